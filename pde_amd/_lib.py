@@ -1,0 +1,77 @@
+"""ctypes binding of libpde_amd.so (the C ABI declared in include/pde_amd.h).
+
+There is no CPU implementation behind this module: if the shared library is missing the import
+of any compute entry point raises.  `torch` is imported first so that the HIP runtime the library
+binds to is the one PyTorch already loaded (same SONAME), which makes torch streams and device
+pointers valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares libamdhip64 with the extension)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpde_amd.so")
+
+MAX_FIELDS, MAX_EQS, MAX_AUX, MAX_SPARAMS, MAX_CONSTS = 4, 4, 1, 3, 16
+
+
+class Problem(C.Structure):
+    _fields_ = [("pde_id", C.c_int32), ("batch", C.c_int32), ("frames", C.c_int32),
+                ("n", C.c_int32 * 3), ("lo", C.c_int32 * 3), ("hi", C.c_int32 * 3),
+                ("n_consts", C.c_int32), ("consts", C.c_float * MAX_CONSTS)]
+
+
+class PdeInfo(C.Structure):
+    _fields_ = [("id", C.c_int32), ("ndim", C.c_int32), ("n_fields", C.c_int32), ("n_eqs", C.c_int32),
+                ("n_aux", C.c_int32), ("n_consts", C.c_int32), ("n_sparams", C.c_int32),
+                ("t_lo", C.c_int32), ("t_hi", C.c_int32), ("halo", C.c_int32 * 3), ("name", C.c_char_p)]
+
+
+_lib = None
+
+# every exported symbol with its signature; tests check that the library exports exactly these
+SIGNATURES = {
+    "pde_amd_num_pdes": (C.c_int, []),
+    "pde_amd_pde_id": (C.c_int, [C.c_char_p]),
+    "pde_amd_get_pde_info": (C.c_int, [C.c_int, C.POINTER(PdeInfo)]),
+    "pde_amd_status_string": (C.c_char_p, [C.c_int]),
+    "pde_amd_residual_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
+    "pde_amd_residual_forward": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pde_amd_residual_backward": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"pde_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = lib().pde_amd_status_string(status).decode()
+        raise RuntimeError(f"pde_amd: {what} failed: {msg} ({status})")
+
+
+def ptr_array(tensors, n):
+    arr = (C.c_void_p * max(n, 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,212 @@
+// C ABI (include/pde_amd.h) over the stencil kernels: validation, geometry, launches.
+#include "../../include/pde_amd.h"
+#include "stencil_kernels.hpp"
+#include <string.h>
+
+namespace pde_amd {
+#include "gen/registry.inc"
+
+static_assert(MAXF == PDE_AMD_MAX_FIELDS && MAXE == PDE_AMD_MAX_EQS && MAXA == PDE_AMD_MAX_AUX &&
+              MAXSP == PDE_AMD_MAX_SPARAMS && MAXC == PDE_AMD_MAX_CONSTS, "header and kernel limits differ");
+
+struct PdeVTable {
+  pde_amd_pde_info info;
+  size_t (*ws_bytes)(const pde_amd_problem*);
+  int (*fwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
+             double*, float* const*, void*, size_t, hipStream_t);
+  int (*bwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
+             const float* const*, float* const*, void*, size_t, hipStream_t);
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+template <class P>
+struct Ops {
+  static bool fill_geom(const pde_amd_problem* p, Geom& g, int t0, int t1, int t2) {
+    g.B = p->batch; g.T = p->frames; g.TR = p->frames - P::TLO - P::THI;
+    g.N0 = p->n[0]; g.N1 = p->n[1]; g.N2 = p->n[2];
+    g.lo0 = p->lo[0]; g.lo1 = p->lo[1]; g.lo2 = p->lo[2];
+    g.hi0 = p->hi[0]; g.hi1 = p->hi[1]; g.hi2 = p->hi[2];
+    g.nt0 = cdiv(g.N0, t0); g.nt1 = cdiv(g.N1, t1); g.nt2 = cdiv(g.N2, t2);
+    g.S = (long)g.N0 * g.N1 * g.N2;
+    return true;
+  }
+
+  static int check(const pde_amd_problem* p) {
+    if (p->n_consts != P::NC) return PDE_AMD_EINVAL;
+    if (p->batch < 1 || p->frames < 1 || p->n[0] < 1 || p->n[1] < 1 || p->n[2] < 1) return PDE_AMD_ESHAPE;
+    if (P::ND < 3 && p->n[0] != 1) return PDE_AMD_ESHAPE;
+    if (P::ND < 2 && p->n[1] != 1) return PDE_AMD_ESHAPE;
+    if ((long)p->n[0] * p->n[1] * p->n[2] >= (1L << 31)) return PDE_AMD_ESHAPE;
+    // a periodic axis must be at least as long as the widest halo any tile loads along it
+    const int h0 = max3(P::RH0, P::GH0, P::AH0), h1 = max3(P::RH1, P::GH1, P::AH1), h2 = max3(P::RH2, P::GH2, P::AH2);
+    if (P::PER0 && p->n[0] < h0) return PDE_AMD_ESHAPE;
+    if (P::PER1 && p->n[1] < h1) return PDE_AMD_ESHAPE;
+    if (P::PER2 && p->n[2] < h2) return PDE_AMD_ESHAPE;
+    for (int a = 0; a < 3; ++a)
+      if (p->lo[a] < 0 || p->hi[a] < 0) return PDE_AMD_EINVAL;
+    return PDE_AMD_OK;
+  }
+
+  static long fwd_items(const pde_amd_problem* p) {
+    const long tr = p->frames - P::TLO - P::THI;
+    if (tr <= 0) return 0;
+    return tr * cdiv(p->n[0], P::FT0) * cdiv(p->n[1], P::FT1) * cdiv(p->n[2], P::FT2);
+  }
+
+  static size_t ws_bytes(const pde_amd_problem* p) {
+    return (size_t)(p->batch * fwd_items(p)) * P::NE * sizeof(double) + 256;
+  }
+
+  static void fill_args(Args& a, const pde_amd_problem* p, const float* const* fields, const float* const* aux,
+                        const float* const* sparams) {
+    memset(&a, 0, sizeof(a));
+    for (int f = 0; f < P::NF; ++f) a.f[f] = fields[f];
+    for (int x = 0; x < P::NA; ++x) a.aux[x] = aux[x];
+    for (int s = 0; s < P::NSP; ++s) a.sp[s] = sparams[s];
+    for (int c = 0; c < P::NC; ++c) a.c[c] = p->consts[c];
+  }
+
+  static int fwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
+                 const float* const* sparams, const float* weights, double* sums, float* const* resid_out,
+                 void* ws, size_t ws_bytes_given, hipStream_t stream) {
+    int st = check(p);
+    if (st) return st;
+    if (!fields || !weights || !sums || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
+    const long items = fwd_items(p);
+    if (items <= 0) {   // no residual frame: the sums are empty sums
+      (void)hipMemsetAsync(sums, 0, sizeof(double) * p->batch * P::NE, stream);
+      return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+    }
+    if (!ws || ws_bytes_given < ws_bytes(p)) return PDE_AMD_EWORKSPACE;
+    Args a;
+    fill_args(a, p, fields, aux, sparams);
+    fill_geom(p, a.geo, P::FT0, P::FT1, P::FT2);
+    a.wt = weights;
+    a.partial = reinterpret_cast<double*>(ws);
+    const long nwg = (long)p->batch * items;
+    if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+    if (resid_out) {
+      for (int k = 0; k < P::NE; ++k) {
+        if (!resid_out[k]) return PDE_AMD_EINVAL;
+        a.rout[k] = resid_out[k];
+      }
+      hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((fwd_kernel<P, false>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+    }
+    hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(p->batch), dim3(256), 0, stream, a.partial, sums, (int)items);
+    return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+  }
+
+  static int bwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
+                 const float* const* sparams, const float* coef, const float* const* resid_in,
+                 float* const* grads, void* ws, size_t ws_bytes_given, hipStream_t stream) {
+    int st = check(p);
+    if (st) return st;
+    if (!fields || !coef || !grads || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
+    const long tr = p->frames - P::TLO - P::THI;
+    if (tr <= 0) {      // the loss does not depend on the fields
+      for (int f = 0; f < P::NF; ++f)
+        (void)hipMemsetAsync(grads[f], 0, sizeof(float) * (size_t)p->batch * p->frames * p->n[0] * p->n[1] * p->n[2], stream);
+      return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+    }
+    if (!resid_in) return PDE_AMD_EINVAL;   // recompute mode is not built for this PDE
+    Args a;
+    fill_args(a, p, fields, aux, sparams);
+    fill_geom(p, a.geo, P::BT0, P::BT1, P::BT2);
+    a.wt = coef;
+    for (int k = 0; k < P::NE; ++k) {
+      if (!resid_in[k]) return PDE_AMD_EINVAL;
+      a.r[k] = resid_in[k];
+    }
+    for (int f = 0; f < P::NF; ++f) {
+      if (!grads[f]) return PDE_AMD_EINVAL;
+      a.g[f] = grads[f];
+    }
+    const long nwg = (long)p->batch * p->frames * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+    if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+    hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+    (void)ws; (void)ws_bytes_given;
+    return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+  }
+
+  static PdeVTable vtable() {
+    PdeVTable v;
+    v.info.id = P::ID; v.info.ndim = P::ND; v.info.n_fields = P::NF; v.info.n_eqs = P::NE; v.info.n_aux = P::NA;
+    v.info.n_consts = P::NC; v.info.n_sparams = P::NSP; v.info.t_lo = P::TLO; v.info.t_hi = P::THI;
+    v.info.halo[0] = P::RH0 > P::RT0 ? P::RH0 : P::RT0;
+    v.info.halo[1] = P::RH1 > P::RT1 ? P::RH1 : P::RT1;
+    v.info.halo[2] = P::RH2 > P::RT2 ? P::RH2 : P::RT2;
+    v.info.name = P::NAME;
+    v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd;
+    return v;
+  }
+};
+
+#define PDE_AMD_VT(P) Ops<P>::vtable(),
+static const PdeVTable kTable[] = {PDE_AMD_FOR_EACH_PDE(PDE_AMD_VT)};
+static constexpr int kNumPdes = sizeof(kTable) / sizeof(kTable[0]);
+
+static const PdeVTable* lookup(int id) {
+  if (id < 0 || id >= kNumPdes) return nullptr;
+  return &kTable[id];
+}
+}  // namespace pde_amd
+
+using namespace pde_amd;
+
+extern "C" {
+
+int pde_amd_num_pdes(void) { return kNumPdes; }
+
+int pde_amd_pde_id(const char* name) {
+  if (!name) return PDE_AMD_EINVAL;
+  for (int i = 0; i < kNumPdes; ++i)
+    if (strcmp(kTable[i].info.name, name) == 0) return i;
+  return PDE_AMD_EINVAL;
+}
+
+int pde_amd_get_pde_info(int pde_id, pde_amd_pde_info* out) {
+  const PdeVTable* v = lookup(pde_id);
+  if (!v || !out) return PDE_AMD_EINVAL;
+  *out = v->info;
+  return PDE_AMD_OK;
+}
+
+const char* pde_amd_status_string(int status) {
+  switch (status) {
+    case PDE_AMD_OK: return "ok";
+    case PDE_AMD_EINVAL: return "invalid argument";
+    case PDE_AMD_ESHAPE: return "unsupported shape";
+    case PDE_AMD_EWORKSPACE: return "workspace too small";
+    case PDE_AMD_EHIP: return "HIP launch failed";
+    default: return "unknown status";
+  }
+}
+
+size_t pde_amd_residual_workspace_bytes(const pde_amd_problem* prob) {
+  const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
+  return v ? v->ws_bytes(prob) : 0;
+}
+
+int pde_amd_residual_forward(const pde_amd_problem* prob, const float* const* fields, const float* const* aux,
+                             const float* const* sparams, const float* weights, double* sums,
+                             float* const* resid_out, void* workspace, size_t workspace_bytes, void* stream) {
+  const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
+  if (!v) return PDE_AMD_EINVAL;
+  return v->fwd(prob, fields, aux, sparams, weights, sums, resid_out, workspace, workspace_bytes,
+                static_cast<hipStream_t>(stream));
+}
+
+int pde_amd_residual_backward(const pde_amd_problem* prob, const float* const* fields, const float* const* aux,
+                              const float* const* sparams, const float* coef, const float* const* resid_in,
+                              float* const* grads, void* workspace, size_t workspace_bytes, void* stream) {
+  const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
+  if (!v) return PDE_AMD_EINVAL;
+  return v->bwd(prob, fields, aux, sparams, coef, resid_in, grads, workspace, workspace_bytes,
+                static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

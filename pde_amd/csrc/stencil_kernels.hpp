@@ -1,0 +1,451 @@
+// Hand-written gfx950 kernel skeletons for finite-difference residual losses and their adjoints.
+//
+// A PDE is a traits struct (csrc/gen/pde_*.inc) that supplies the residual of every equation at one
+// lattice site and the gather-form adjoint at one grid point, both written against an accessor.
+// The skeletons here own everything else: LDS halo tiles with periodic wrap or wall fill, the
+// work -> (sample, frame, tile) map, fp64 wave/block reductions without atomics, and the stores.
+//
+// Layout: every field is a contiguous fp32 tensor [B, T, N0, N1, N2] (unused leading axes = 1).
+// A workgroup owns one spatial tile of one frame; a wave covers 64 consecutive points along the
+// fastest axis, so global loads/stores are coalesced 256-byte rows and LDS reads are conflict-free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pde_amd {
+
+constexpr int MAXF = 4;    // fields
+constexpr int MAXE = 4;    // equations
+constexpr int MAXA = 1;    // time-independent auxiliary fields
+constexpr int MAXSP = 3;   // per-sample parameters
+constexpr int MAXC = 16;   // per-instance constants
+
+struct Geom {
+  int B, T, TR;                        // samples, frames, residual frames (T - TLO - THI)
+  int N0, N1, N2;                      // spatial extents
+  int lo0, lo1, lo2, hi0, hi1, hi2;    // residual lattice: lo <= index < N - hi
+  int nt0, nt1, nt2;                   // tiles per axis
+  long S;                              // N0 * N1 * N2
+};
+
+struct Args {
+  const float* f[MAXF];
+  const float* aux[MAXA];
+  const float* sp[MAXSP];
+  const float* r[MAXE];    // stored residuals [B, TR, S] per equation (backward, stored mode)
+  float* rout[MAXE];       // residual output (forward, optional)
+  float* g[MAXF];          // gradients
+  const float* wt;         // forward: weights [NE][TR]; backward: coefficients [B][NE][TR]
+  double* partial;         // forward: per-workgroup partial sums [nwg][NE]
+  float c[MAXC];
+  Geom geo;
+};
+
+// ------------------------------------------------------------------------------------------------
+// tiles
+// ------------------------------------------------------------------------------------------------
+template <int T0_, int T1_, int T2_, int H0_, int H1_, int H2_>
+struct Tile {
+  static constexpr int T0 = T0_, T1 = T1_, T2 = T2_, H0 = H0_, H1 = H1_, H2 = H2_;
+  static constexpr int D0 = T0 + 2 * H0, D1 = T1 + 2 * H1, D2 = T2 + 2 * H2;
+  static constexpr int S1 = D2, S0 = D1 * D2, SIZE = D0 * D1 * D2;
+  __device__ static __forceinline__ int at(int l0, int l1, int l2) {
+    return (l0 + H0) * S0 + (l1 + H1) * S1 + (l2 + H2);
+  }
+};
+
+template <bool PER>
+__device__ __forceinline__ int wrap_coord(int c, int N, bool& ok) {
+  if (PER) {
+    if (c < 0) c += N;
+    else if (c >= N) c -= N;
+    c = min(max(c, 0), N - 1);   // beyond one period: only reachable from sites outside the grid
+  } else {
+    if (c < 0 || c >= N) { ok = false; c = 0; }
+  }
+  return c;
+}
+
+// Fill one LDS tile (with halo) from one frame of one field. Out-of-grid points of a wall axis read 0.
+template <class TL, bool P0, bool P1, bool P2, int NT>
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src,
+                                          int o0, int o1, int o2, const Geom& g, float scale) {
+  for (int i = threadIdx.x; i < TL::SIZE; i += NT) {
+    const int l2 = i % TL::D2, rr = i / TL::D2, l1 = rr % TL::D1, l0 = rr / TL::D1;
+    bool ok = true;
+    const int c0 = wrap_coord<P0>(o0 + l0 - TL::H0, g.N0, ok);
+    const int c1 = wrap_coord<P1>(o1 + l1 - TL::H1, g.N1, ok);
+    const int c2 = wrap_coord<P2>(o2 + l2 - TL::H2, g.N2, ok);
+    float v = 0.0f;
+    if (ok) v = src[((long)c0 * g.N1 + c1) * g.N2 + c2] * scale;
+    dst[i] = v;
+  }
+}
+
+template <class TL, int NT>
+__device__ __forceinline__ void zero_tile(float* dst) {
+  for (int i = threadIdx.x; i < TL::SIZE; i += NT) dst[i] = 0.0f;
+}
+
+// Blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous run of work items so that
+// neighbouring tiles, which share halos, meet in one L2. Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int pid, int n) {
+  const int q = n >> 3, r = n & 7, x = pid & 7, s = pid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// accessors handed to the generated residual / adjoint code
+// ------------------------------------------------------------------------------------------------
+template <class P>
+struct SiteBase {
+  const float* cc;           // constants
+  float spv[MAXSP];          // per-sample parameters of this sample
+  int i0, i1, i2, N0, N1, N2;
+  __device__ __forceinline__ float c(int i) const { return cc[i]; }
+  __device__ __forceinline__ float sp(int i) const { return spv[i]; }
+  __device__ __forceinline__ bool at(int axis, int k) const { return (axis == 0 ? i0 : axis == 1 ? i1 : i2) == k; }
+  __device__ __forceinline__ bool ath(int axis, int k) const {
+    return axis == 0 ? (i0 == N0 - 1 - k) : axis == 1 ? (i1 == N1 - 1 - k) : (i2 == N2 - 1 - k);
+  }
+};
+
+// Residual evaluation: ot == 0 reads the halo tile; ot != 0 reads a time tile when the PDE has spatial
+// offsets at other frames, else the same grid point of the neighbouring frame straight from global memory.
+template <class P, class TL, class TT, class TX>
+struct ResAcc : SiteBase<P> {
+  const float* lds;          // &tile_f0[site]
+  const float* ldst;         // &time_tile_f0_slot0[site]
+  const float* ldsx;         // &aux_tile[site]
+  const float* fp[MAXF];     // field pointers at (b, frame, 0)
+  long S;
+  int goff;
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    if (ot == 0) return lds[f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + o2];
+    if ((P::RT0 | P::RT1 | P::RT2) != 0) {
+      const int slot = ot < 0 ? ot + P::TLO : ot + P::TLO - 1;
+      return ldst[(slot * P::NF + f) * TT::SIZE + o0 * TT::S0 + o1 * TT::S1 + o2];
+    }
+    return fp[f][goff + (long)ot * S];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    return ldsx[x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + o2];
+  }
+  __device__ __forceinline__ float G(int, int, int, int, int) const { return 0.0f; }
+};
+
+// Adjoint evaluation at an output point of frame tq.
+template <class P, class TG, class TGT, class TA, class TAT, class TX>
+struct AdjAcc : SiteBase<P> {
+  static constexpr int NG = P::GTLO + P::GTHI + 1;
+  const float* ldsg;         // G tile of frame tq
+  const float* ldsgt;        // G tiles of the other frames (when they need a halo)
+  const float* ldsa;         // F tile of frame tq
+  const float* ldsat;        // F tiles of the other frames (when they need a halo)
+  const float* ldsx;
+  const float* fp[MAXF];     // field pointers at (b, tq, 0)
+  const float* rp[MAXE];     // stored-residual pointers at (b, 0, 0)
+  float cf[NG][MAXE];        // coefficient of each needed residual frame (0 when that frame is outside the lattice)
+  int tr0;                   // residual-frame index of tq (tq - TLO)
+  int tq, T;
+  long S;
+  int goff;
+  __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
+    if (ot == 0) return ldsg[k * TG::SIZE + o0 * TG::S0 + o1 * TG::S1 + o2];
+    if ((P::GT0 | P::GT1 | P::GT2) != 0) {
+      const int slot = ot < 0 ? ot + P::GTLO : ot + P::GTLO - 1;
+      return ldsgt[(slot * P::NE + k) * TGT::SIZE + o0 * TGT::S0 + o1 * TGT::S1 + o2];
+    }
+    const float cfk = cf[ot + P::GTLO][k];
+    return cfk != 0.0f ? cfk * rp[k][(long)(tr0 + ot) * S + goff] : 0.0f;
+  }
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    if (ot == 0) return ldsa[f * TA::SIZE + o0 * TA::S0 + o1 * TA::S1 + o2];
+    if ((P::AT0 | P::AT1 | P::AT2) != 0) {
+      const int slot = ot < 0 ? ot + P::ATLO : ot + P::ATLO - 1;
+      return ldsat[(slot * P::NF + f) * TAT::SIZE + o0 * TAT::S0 + o1 * TAT::S1 + o2];
+    }
+    return ((unsigned)(tq + ot) < (unsigned)T) ? fp[f][goff + (long)ot * S] : 0.0f;
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    return ldsx[x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + o2];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// reductions: 64-lane shuffle tree, then one LDS slot per wave, no atomics, fixed order
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <int NE, int NT>
+__device__ __forceinline__ void block_sum_store(const double (&acc)[NE], double* red, double* out) {
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wv * NE + k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NE) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * NE + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+template <class P, class TL>
+__device__ __forceinline__ void point_coords(int k, int& l0, int& l1, int& l2) {
+  // a thread owns PPT consecutive rows of one tile column
+  constexpr int PPT = (TL::T0 * TL::T1 * TL::T2) / P::NT;
+  const int row = (threadIdx.x / TL::T2) * PPT + k;
+  l2 = threadIdx.x % TL::T2;
+  l1 = row % TL::T1;
+  l0 = row / TL::T1;
+}
+
+template <class P>
+__device__ __forceinline__ bool in_lattice(const Geom& g, int i0, int i1, int i2) {
+  return i0 >= g.lo0 && i0 < g.N0 - g.hi0 && i1 >= g.lo1 && i1 < g.N1 - g.hi1 && i2 >= g.lo2 && i2 < g.N2 - g.hi2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: one workgroup = (sample, residual frame, tile)
+//   sums of wt[k][frame] * R_k^2 over the tile -> partial[work][k];   optional store of R_k
+// ------------------------------------------------------------------------------------------------
+template <class P, bool WRITE_R>
+__global__ __launch_bounds__(P::NT) void fwd_kernel(const Args a) {
+  using TL = Tile<P::FT0, P::FT1, P::FT2, P::RH0, P::RH1, P::RH2>;
+  using TT = Tile<P::FT0, P::FT1, P::FT2, P::RT0, P::RT1, P::RT2>;
+  using TX = Tile<P::FT0, P::FT1, P::FT2, P::XH0, P::XH1, P::XH2>;
+  constexpr bool TT_ON = (P::RT0 | P::RT1 | P::RT2) != 0;
+  constexpr bool AUX_ON = P::NA > 0;
+  constexpr int NT = P::NT;
+  constexpr int PPT = (TL::T0 * TL::T1 * TL::T2) / NT;
+  static_assert(PPT * NT == TL::T0 * TL::T1 * TL::T2, "tile must be a multiple of the workgroup");
+  static_assert(NT % TL::T2 == 0, "a wave must lie along the fastest axis");
+
+  __shared__ float s_f[P::NF * TL::SIZE];
+  __shared__ float s_t[TT_ON ? (P::TLO + P::THI) * P::NF * TT::SIZE : 1];
+  __shared__ float s_x[AUX_ON ? P::NA * TX::SIZE : 1];
+  __shared__ double s_red[(NT / 64) * P::NE];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int tile = w % ntile, rest = w / ntile;
+  const int tr = rest % g.TR, b = rest / g.TR;
+  const int tau = tr + P::TLO;
+  const int o2 = (tile % g.nt2) * TL::T2, o1 = ((tile / g.nt2) % g.nt1) * TL::T1, o0 = (tile / (g.nt2 * g.nt1)) * TL::T0;
+  const long frame = ((long)b * g.T + tau) * g.S;
+
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f)
+    load_tile<TL, P::PER0, P::PER1, P::PER2, NT>(s_f + f * TL::SIZE, a.f[f] + frame, o0, o1, o2, g, 1.0f);
+  if (TT_ON) {
+#pragma unroll
+    for (int s = 0; s < P::TLO + P::THI; ++s) {
+      const int ot = s < P::TLO ? s - P::TLO : s - P::TLO + 1;
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f)
+        load_tile<TT, P::PER0, P::PER1, P::PER2, NT>(s_t + (s * P::NF + f) * TT::SIZE, a.f[f] + frame + ot * g.S, o0, o1, o2, g, 1.0f);
+    }
+  }
+  if (AUX_ON) {
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x)
+      load_tile<TX, P::PER0, P::PER1, P::PER2, NT>(s_x + x * TX::SIZE, a.aux[x] + (long)b * g.S, o0, o1, o2, g, 1.0f);
+  }
+  __syncthreads();
+
+  ResAcc<P, TL, TT, TX> acc;
+  acc.cc = a.c;
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = a.sp[i][b];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) acc.fp[f] = a.f[f] + frame;
+  acc.S = g.S; acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
+
+  float wk[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) wk[k] = a.wt[k * g.TR + tr];
+
+  double sum[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) sum[k] = 0.0;
+
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    int l0, l1, l2;
+    point_coords<P, TL>(p, l0, l1, l2);
+    const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+    const bool inside = i0 < g.N0 && i1 < g.N1 && i2 < g.N2;
+    const bool active = inside && in_lattice<P>(g, i0, i1, i2);
+    const int goff = (i0 * g.N1 + i1) * g.N2 + i2;
+    float R[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) R[k] = 0.0f;
+    if (active) {
+      acc.i0 = i0; acc.i1 = i1; acc.i2 = i2; acc.goff = goff;
+      acc.lds = s_f + TL::at(l0, l1, l2);
+      acc.ldst = s_t + TT::at(l0, l1, l2);
+      acc.ldsx = s_x + TX::at(l0, l1, l2);
+      P::residual(acc, R);
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) sum[k] += (double)R[k] * (double)R[k] * (double)wk[k];
+    }
+    if (WRITE_R && inside) {
+      const long ro = ((long)b * g.TR + tr) * g.S + goff;
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) a.rout[k][ro] = R[k];
+    }
+  }
+  block_sum_store<P::NE, NT>(sum, s_red, a.partial + (long)w * P::NE);
+}
+
+// partial[b][items][NE] -> sums[b][NE], fixed summation order
+template <int NE>
+__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ partial, double* __restrict__ sums, int items) {
+  __shared__ double red[4 * NE];
+  const int b = blockIdx.x;
+  double acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+  const double* p = partial + (long)b * items * NE;
+  for (int i = threadIdx.x; i < items; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) acc[k] += p[(long)i * NE + k];
+  }
+  block_sum_store<NE, 256>(acc, red, sums + (long)b * NE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, stored-residual mode: one workgroup = (sample, output frame tq, tile)
+//   G_k = coef[b][k][frame] * R_k is staged in LDS (with the adjoint's halo) and gathered
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::NT) void bwd_stored_kernel(const Args a) {
+  using TG = Tile<P::BT0, P::BT1, P::BT2, P::GH0, P::GH1, P::GH2>;
+  using TGT = Tile<P::BT0, P::BT1, P::BT2, P::GT0, P::GT1, P::GT2>;
+  using TA = Tile<P::BT0, P::BT1, P::BT2, P::AH0, P::AH1, P::AH2>;
+  using TAT = Tile<P::BT0, P::BT1, P::BT2, P::AT0, P::AT1, P::AT2>;
+  using TX = Tile<P::BT0, P::BT1, P::BT2, P::XH0, P::XH1, P::XH2>;
+  constexpr bool GT_ON = (P::GT0 | P::GT1 | P::GT2) != 0;
+  constexpr bool AT_ON = (P::AT0 | P::AT1 | P::AT2) != 0;
+  constexpr bool AF_ON = P::ANY_AF != 0;
+  constexpr bool AUX_ON = P::NA > 0;
+  constexpr int NT = P::NT;
+  constexpr int PPT = (TG::T0 * TG::T1 * TG::T2) / NT;
+  constexpr int NGT = P::GTLO + P::GTHI, NAT = P::ATLO + P::ATHI;
+  static_assert(PPT * NT == TG::T0 * TG::T1 * TG::T2, "tile must be a multiple of the workgroup");
+  static_assert(NT % TG::T2 == 0, "a wave must lie along the fastest axis");
+
+  __shared__ float s_g[P::NE * TG::SIZE];
+  __shared__ float s_gt[GT_ON ? NGT * P::NE * TGT::SIZE : 1];
+  __shared__ float s_a[AF_ON ? P::NF * TA::SIZE : 1];
+  __shared__ float s_at[AT_ON ? (NAT > 0 ? NAT : 1) * P::NF * TAT::SIZE : 1];
+  __shared__ float s_x[AUX_ON ? P::NA * TX::SIZE : 1];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int tile = w % ntile, rest = w / ntile;
+  const int tq = rest % g.T, b = rest / g.T;
+  const int o2 = (tile % g.nt2) * TG::T2, o1 = ((tile / g.nt2) % g.nt1) * TG::T1, o0 = (tile / (g.nt2 * g.nt1)) * TG::T0;
+  const long frame = ((long)b * g.T + tq) * g.S;
+
+  AdjAcc<P, TG, TGT, TA, TAT, TX> acc;
+  acc.cc = a.c;
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = a.sp[i][b];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) acc.fp[f] = a.f[f] + frame;
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) acc.rp[k] = a.r[k] + (long)b * g.TR * g.S;
+  acc.S = g.S; acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
+  acc.tq = tq; acc.T = g.T; acc.tr0 = tq - P::TLO;
+
+  // coefficients of the residual frames this output frame touches
+#pragma unroll
+  for (int s = 0; s < P::GTLO + P::GTHI + 1; ++s) {
+    const int trs = tq + (s - P::GTLO) - P::TLO;
+    const bool ok = trs >= 0 && trs < g.TR;
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) acc.cf[s][k] = ok ? a.wt[((long)b * P::NE + k) * g.TR + trs] : 0.0f;
+  }
+
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) {
+    const float cfk = acc.cf[P::GTLO][k];
+    if (cfk != 0.0f)
+      load_tile<TG, P::PER0, P::PER1, P::PER2, NT>(s_g + k * TG::SIZE, acc.rp[k] + (long)acc.tr0 * g.S, o0, o1, o2, g, cfk);
+    else
+      zero_tile<TG, NT>(s_g + k * TG::SIZE);
+  }
+  if (GT_ON) {
+#pragma unroll
+    for (int s = 0; s < NGT; ++s) {
+      const int ot = s < P::GTLO ? s - P::GTLO : s - P::GTLO + 1;
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) {
+        const float cfk = acc.cf[ot + P::GTLO][k];
+        float* dst = s_gt + (s * P::NE + k) * TGT::SIZE;
+        if (cfk != 0.0f)
+          load_tile<TGT, P::PER0, P::PER1, P::PER2, NT>(dst, acc.rp[k] + (long)(acc.tr0 + ot) * g.S, o0, o1, o2, g, cfk);
+        else
+          zero_tile<TGT, NT>(dst);
+      }
+    }
+  }
+  if (AF_ON) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f)
+      load_tile<TA, P::PER0, P::PER1, P::PER2, NT>(s_a + f * TA::SIZE, a.f[f] + frame, o0, o1, o2, g, 1.0f);
+  }
+  if (AT_ON) {
+#pragma unroll
+    for (int s = 0; s < NAT; ++s) {
+      const int ot = s < P::ATLO ? s - P::ATLO : s - P::ATLO + 1;
+      const bool ok = (unsigned)(tq + ot) < (unsigned)g.T;
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) {
+        float* dst = s_at + (s * P::NF + f) * TAT::SIZE;
+        if (ok) load_tile<TAT, P::PER0, P::PER1, P::PER2, NT>(dst, a.f[f] + frame + (long)ot * g.S, o0, o1, o2, g, 1.0f);
+        else zero_tile<TAT, NT>(dst);
+      }
+    }
+  }
+  if (AUX_ON) {
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x)
+      load_tile<TX, P::PER0, P::PER1, P::PER2, NT>(s_x + x * TX::SIZE, a.aux[x] + (long)b * g.S, o0, o1, o2, g, 1.0f);
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    int l0, l1, l2;
+    point_coords<P, TG>(p, l0, l1, l2);
+    const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+    if (i0 < g.N0 && i1 < g.N1 && i2 < g.N2) {
+      acc.i0 = i0; acc.i1 = i1; acc.i2 = i2;
+      acc.goff = (i0 * g.N1 + i1) * g.N2 + i2;
+      acc.ldsg = s_g + TG::at(l0, l1, l2);
+      acc.ldsgt = s_gt + TGT::at(l0, l1, l2);
+      acc.ldsa = s_a + TA::at(l0, l1, l2);
+      acc.ldsat = s_at + TAT::at(l0, l1, l2);
+      acc.ldsx = s_x + TX::at(l0, l1, l2);
+      float gr[P::NF];
+      P::adjoint(acc, gr);
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) a.g[f][frame + acc.goff] = gr[f];
+    }
+  }
+}
+
+}  // namespace pde_amd

@@ -1,0 +1,721 @@
+"""PDE-residual loss modules with the reference's constructor / forward signatures.
+
+Each class mirrors one `nn.Module` of the reference's finetune/pde_loss_verified.py (cited per class):
+same constructor arguments and defaults, same `forward` arguments, same returned
+`(total, {equation: loss})` with the same dict keys, same public attributes (`eq_scales`,
+`eq_weights`, `use_per_t_scales` / `has_per_t_scales`, `scales_t_<eq>` buffers).  The arithmetic runs in
+the gfx950 stencil kernels through `pde_amd.functional.residual_sums`; the host code below only turns
+scales / weights / per-timestep scales into the `[n_eqs, T_res]` weight table the kernels consume.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .functional import StencilProblem, residual_sums
+from .stencil.specs import SPECS
+
+Tensor = torch.Tensor
+
+
+class StencilPDELoss(nn.Module):
+    """Shared host logic: weight table, per-sample parameter defaults, result dict."""
+
+    SPEC: str = ""
+    EQS: Sequence[str] = ()                 # dict keys, in the reference's insertion order
+    GUARDED: Sequence[str] = ()             # equations skipped (exact 0.0, no gradient) when their weight is <= 0
+    PER_T: str = "none"                     # 'helper': _get_per_t_scale(+t_offset); 'slice': scales_t_X[:T_res]; 'none'
+    PER_T_FLAG: str = "use_per_t_scales"    # attribute name the reference exposes
+    PER_T_EQS: Optional[Sequence[str]] = None   # equations that honour per-t scales (None = all)
+    PER_T_ALIAS: Dict[str, str] = {}        # equation -> buffer suffix when they differ
+    TOTAL_KEY: bool = False                 # whether the dict carries 'total'
+    SCALE_KEYS: Dict[str, str] = {}         # equation -> key looked up in eq_scales / eq_weights when they differ
+    backward_mode = "stored"
+
+    def _init_common(self, default_scales, eq_scales, eq_weights, eq_scales_per_t, per_t_supported=True):
+        self.eq_scales = {**default_scales, **(eq_scales or {})}
+        self.eq_weights = {**{k: 1.0 for k in default_scales}, **(eq_weights or {})}
+        if per_t_supported:
+            setattr(self, self.PER_T_FLAG, eq_scales_per_t is not None)
+            if eq_scales_per_t is not None:
+                for name, scales in eq_scales_per_t.items():
+                    self.register_buffer(f"scales_t_{name}", torch.as_tensor(scales).float())
+        self._wt_cache = {}
+
+    # -- to be provided by subclasses -------------------------------------------------------------
+    def _params(self) -> Dict[str, float]:
+        raise NotImplementedError
+
+    def _lattice(self, spatial: Sequence[int]) -> Tuple[Tuple[int, int, int], Tuple[int, int, int]]:
+        return (0, 0, 0), (0, 0, 0)
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _problem(self, spatial) -> StencilProblem:
+        spec = SPECS[self.SPEC]
+        p = self._params()
+        consts = [fn(p) for _, fn in spec.consts]
+        lo, hi = self._lattice(spatial)
+        return StencilProblem(self.SPEC, consts, lo, hi)
+
+    def _per_t_scale(self, eq: str, T_res: int, t_offset: Optional[Tensor]) -> Optional[Tensor]:
+        """The [T_res] scale vector the reference would divide by, or None for the fixed scale."""
+        if self.PER_T == "none" or not getattr(self, self.PER_T_FLAG, False):
+            return None
+        if self.PER_T_EQS is not None and eq not in self.PER_T_EQS:
+            return None
+        buf = getattr(self, f"scales_t_{self.PER_T_ALIAS.get(eq, eq)}", None)
+        if buf is None:
+            return None
+        if self.PER_T == "slice":                      # e.g. :2487-2490
+            if buf.shape[0] < T_res:
+                raise ValueError(f"scales_t_{eq} has {buf.shape[0]} entries, fewer than the {T_res} residual frames")
+            return buf[:T_res].clamp(min=1e-8)
+        # 'helper' = _get_per_t_scale, :854-901
+        T_full = buf.shape[0]
+        if t_offset is not None:
+            off = t_offset.to(device=buf.device, dtype=torch.long).view(-1)
+            ok = (off >= 0) & (off + T_res <= T_full)
+            clamped = off.clamp(max=T_full - T_res).clamp(min=0)
+            start = torch.where(ok, off, clamped)
+            idx = start[:, None] + torch.arange(T_res, device=buf.device)[None, :]
+            scale = buf[idx].mean(dim=0)
+        else:
+            scale = buf[:T_res] if T_res <= T_full else buf.mean().expand(T_res)
+        return scale.clamp(min=1e-8)
+
+    def _weights(self, T_res: int, n_sites: int, device, t_offset) -> Tuple[Tensor, List[bool]]:
+        """wt[k, t] = w_k / (s^2 N) with s the fixed or per-timestep scale; zero rows for skipped equations."""
+        key = (T_res, n_sites, str(device)) if t_offset is None else None
+        if key is not None and key in self._wt_cache:
+            return self._wt_cache[key]
+        rows, skipped = [], []
+        for eq in self.EQS:
+            k = self.SCALE_KEYS.get(eq, eq)
+            w = float(self.eq_weights[k])
+            skip = (eq in self.GUARDED) and not (w > 0)
+            skipped.append(skip)
+            if skip or T_res <= 0 or n_sites <= 0:
+                rows.append(torch.zeros(max(T_res, 0), dtype=torch.float64, device=device))
+                continue
+            st = self._per_t_scale(eq, T_res, t_offset)
+            if st is not None:
+                rows.append(w / (st.to(device=device, dtype=torch.float64) ** 2 * n_sites))
+            else:
+                s = self._fixed_scale(eq)
+                rows.append(torch.full((T_res,), w / (s ** 2 * n_sites), dtype=torch.float64, device=device))
+        wt = torch.stack(rows).to(torch.float32) if rows else torch.zeros((0, max(T_res, 0)), device=device)
+        out = (wt, skipped)
+        if key is not None:
+            self._wt_cache[key] = out
+        return out
+
+    def _fixed_scale(self, eq: str) -> float:
+        return float(self.eq_scales[self.SCALE_KEYS.get(eq, eq)])
+
+    def _sample_param(self, value, default, B: int, ref: Tensor) -> Tensor:
+        if value is None:
+            value = default
+        if torch.is_tensor(value):
+            v = value.to(device=ref.device, dtype=torch.float32).reshape(-1)
+            return v.expand(B) if v.numel() == 1 else v
+        return torch.full((B,), float(value), dtype=torch.float32, device=ref.device)
+
+    def _evaluate(self, fields: Sequence[Tensor], sparams: Sequence[Tensor] = (), aux: Sequence[Tensor] = (),
+                  t_offset: Optional[Tensor] = None):
+        spec = SPECS[self.SPEC]
+        f0 = fields[0]
+        if f0.dim() != 2 + spec.ndim:
+            raise ValueError(f"{type(self).__name__}: fields must be [B, T, {spec.ndim} spatial dims], got {tuple(f0.shape)}")
+        B, T = f0.shape[0], f0.shape[1]
+        spatial = list(f0.shape[2:])
+        prob = self._problem(spatial)
+        full = [1] * (3 - spec.ndim) + spatial
+        ext = [max(full[a] - prob.lo[a] - prob.hi[a], 0) for a in range(3)]
+        T_res = T - spec.tlo - spec.thi
+        n_sites = B * max(T_res, 0) * ext[0] * ext[1] * ext[2]
+        wt, skipped = self._weights(T_res, n_sites, f0.device, t_offset)
+        sums = residual_sums(prob, fields, wt, sparams, aux, mode=self.backward_mode)   # [B, n_eqs] fp64
+        per_eq = sums.sum(dim=0).to(torch.float32)
+        losses: Dict[str, Tensor] = {}
+        for k, eq in enumerate(self.EQS):
+            if skipped[k]:
+                losses[eq] = torch.tensor(0.0, device=f0.device)
+            elif n_sites == 0:
+                losses[eq] = per_eq[k] * float("nan")      # mean over an empty lattice
+            else:
+                losses[eq] = per_eq[k]
+        total = sum(losses.values())
+        if self.TOTAL_KEY:
+            losses["total"] = total
+        return total, losses
+
+
+# =================================================================================================
+# 1-D periodic
+# =================================================================================================
+class Burgers1DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:2924-3027"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "burgers1d", ("momentum",), "slice", True
+    DEFAULT_EQ_SCALES = {"momentum": 1.0}
+
+    def __init__(self, dx: float = 2 * np.pi / 256, dt: float = 0.01, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dt = dx, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt)
+
+    def forward(self, u: Tensor, nu: Tensor):
+        return self._evaluate([u], [self._sample_param(nu, None, u.shape[0], u)])
+
+
+class Advection1DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3034-3127"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "advection1d", ("advection",), "slice", True
+    DEFAULT_EQ_SCALES = {"advection": 1.0}
+
+    def __init__(self, dx: float = 2 * np.pi / 256, dt: float = 0.01, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dt = dx, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt)
+
+    def forward(self, u: Tensor, a: Tensor):
+        return self._evaluate([u], [self._sample_param(a, None, u.shape[0], u)])
+
+
+class Heat1DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3134-3229"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "heat1d", ("heat",), "slice", True
+    DEFAULT_EQ_SCALES = {"heat": 1.0}
+
+    def __init__(self, dx: float = 2 * np.pi / 256, dt: float = 0.01, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dt = dx, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt)
+
+    def forward(self, u: Tensor, alpha: Tensor):
+        return self._evaluate([u], [self._sample_param(alpha, None, u.shape[0], u)])
+
+
+class APEBenchBurgers1DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3348-3419"""
+    SPEC, EQS = "ape_burgers1d", ("momentum",)
+    DEFAULT_EQ_SCALES = {"momentum": 1.0}
+
+    def __init__(self, nx: int = 160, Lx: float = 1.0, dt: float = 1.0, alpha_2: float = 2.9297e-5,
+                 delta_conv: float = -4.6875e-3, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.dx, self.dt, self.alpha_2, self.delta_conv = Lx / nx, dt, alpha_2, delta_conv
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt, alpha_2=self.alpha_2, delta_conv=self.delta_conv)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+class KS1DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3535-3649"""
+    SPEC, EQS = "ks1d", ("momentum",)
+    DEFAULT_EQ_SCALES = {"momentum": 1.0}
+
+    def __init__(self, nx: int = 160, Lx: float = 1.0, dt: float = 1.0, alpha_2: float = -2.34375e-5,
+                 alpha_4: float = -2.8610229492e-9, beta_2: float = -2.34375e-4, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.dx, self.dt = Lx / nx, dt
+        self.alpha_2, self.alpha_4, self.beta_2 = alpha_2, alpha_4, beta_2
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt, alpha_2=self.alpha_2, alpha_4=self.alpha_4, beta_2=self.beta_2)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+class KdV1DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3656-3775"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "kdv1d", ("kdv",), "slice", True
+    DEFAULT_EQ_SCALES = {"kdv": 1.0}
+
+    def __init__(self, nx: int = 160, Lx: float = 1.0, dt: float = 1.0, alpha_3: float = -8.5449e-7,
+                 alpha_4: float = -1.7166e-9, beta_1: float = -1.2500e-2, eq_scales=None, eq_weights=None,
+                 eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dt = Lx / nx, dt
+        self.alpha_3, self.alpha_4, self.beta_1 = alpha_3, alpha_4, beta_1
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt, alpha_3=self.alpha_3, alpha_4=self.alpha_4, beta_1=self.beta_1)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+# =================================================================================================
+# 2-D periodic, central differences
+# =================================================================================================
+class TaylorGreen2DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:1717-1923 (dx = Lx / nx runs along dim -1, dy = Ly / ny along dim -2)"""
+    SPEC, EQS = "tg2d", ("continuity", "x_momentum", "y_momentum")
+    GUARDED, PER_T, PER_T_FLAG = ("x_momentum", "y_momentum"), "helper", "has_per_t_scales"
+    DEFAULT_EQ_SCALES = {"continuity": 1.0, "x_momentum": 1.0, "y_momentum": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 256, Lx: float = 6.283185307179586, Ly: float = 6.283185307179586,
+                 dt: float = 0.01, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt = Lx / nx, Ly / ny, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def forward(self, u: Tensor, v: Tensor, p: Tensor, nu: Optional[Tensor] = None, t_offset: Optional[Tensor] = None):
+        return self._evaluate([u, v, p], [self._sample_param(nu, 0.01, u.shape[0], u)], t_offset=t_offset)   # :1853-1856
+
+
+class AdvDiff2DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:2369-2495"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "advdiff2d", ("advdiff",), "slice", True
+    DEFAULT_EQ_SCALES = {"advdiff": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 256, dx: float = 2 * np.pi / 256, dy: float = 2 * np.pi / 256,
+                 dt: float = 0.01, a: float = 1.0, b: float = 0.5, nu: float = 0.05, eq_scales=None, eq_weights=None,
+                 eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny, self.dx, self.dy, self.dt, self.a, self.b, self.nu = nx, ny, dx, dy, dt, a, b, nu
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, a=self.a, b=self.b, nu=self.nu)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+class AnisoDiff2DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:2502-2643"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "anisodiff2d", ("aniso_diff",), "slice", True
+    DEFAULT_EQ_SCALES = {"aniso_diff": 1.0}
+
+    def __init__(self, nx: int = 160, ny: int = 160, dx: float = 1.0 / 160, dy: float = 1.0 / 160, dt: float = 0.1,
+                 A_xx: float = 0.001, A_xy: float = 0.0005, A_yx: float = 0.0005, A_yy: float = 0.002,
+                 eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny, self.dx, self.dy, self.dt = nx, ny, dx, dy, dt
+        self.A_xx, self.A_xy, self.A_yx, self.A_yy = A_xx, A_xy, A_yx, A_yy
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, A_xx=self.A_xx, A_xy=self.A_xy, A_yx=self.A_yx, A_yy=self.A_yy)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+class Wave2DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:2650-2789"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "wave2d", ("u_equation", "w_equation"), "slice", True
+    DEFAULT_EQ_SCALES = {"u_equation": 1.0, "w_equation": 1.0}
+
+    def __init__(self, dx: float = 2 * np.pi / 256, dy: float = 2 * np.pi / 256, dt: float = 0.01, eq_scales=None,
+                 eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dy, self.dt = dx, dy, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def forward(self, u: Tensor, w: Tensor, c: Tensor):
+        c = self._sample_param(c, None, u.shape[0], u)
+        return self._evaluate([u, w], [c * c])          # c^2 in fp32, as :2747
+
+
+class APEBenchBurgers2DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3241-3341"""
+    SPEC, EQS = "ape_burgers2d", ("u_momentum", "v_momentum")
+    DEFAULT_EQ_SCALES = {"u_momentum": 1.0, "v_momentum": 1.0}
+
+    def __init__(self, nx: int = 160, ny: int = 160, Lx: float = 1.0, Ly: float = 1.0, dt: float = 1.0,
+                 alpha_2: float = 1.4648e-5, delta_conv: float = -2.3438e-3, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.dx, self.dy, self.dt, self.alpha_2, self.delta_conv = Lx / nx, Ly / ny, dt, alpha_2, delta_conv
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, alpha_2=self.alpha_2, delta_conv=self.delta_conv)
+
+    def forward(self, u: Tensor, v: Tensor):
+        return self._evaluate([u, v])
+
+
+class NSPwCPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:1576-1710"""
+    SPEC, EQS, GUARDED = "nspwc", ("divergence", "vorticity", "tracer"), ("vorticity", "tracer")
+    DEFAULT_EQ_SCALES = {"divergence": 1.0, "vorticity": 1.0, "tracer": 1.0}
+
+    def __init__(self, nx: int = 128, ny: int = 128, Lx: float = 1.0, Ly: float = 1.0, dt: float = 0.05,
+                 nu: float = 4e-4, kappa: float = 4e-4, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.nu, self.kappa = Lx / nx, Ly / ny, dt, nu, kappa
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, nu=self.nu, kappa=self.kappa)
+
+    def forward(self, u: Tensor, v: Tensor, s: Tensor):
+        return self._evaluate([u, v, s])
+
+
+class KP2DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:1930-2072"""
+    SPEC, EQS, PER_T = "kp2d", ("kp2_equation",), "slice"
+    DEFAULT_EQ_SCALES = {"kp2_equation": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 256, dx: float = 20.0 / 256, dy: float = 20.0 / 256, dt: float = 0.01,
+                 skip_boundary: int = 20, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny, self.dx, self.dy, self.dt, self.skip_boundary = nx, ny, dx, dy, dt, skip_boundary
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def _lattice(self, spatial):
+        sb = max(int(self.skip_boundary), 0)
+        return (0, sb, sb), (0, sb, sb)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+# =================================================================================================
+# 2-D periodic, conservative upwind (n-PINN)
+# =================================================================================================
+class ShearFlowPDELossNPINN(StencilPDELoss):
+    """finetune/pde_loss_verified.py:1146-1470"""
+    SPEC, EQS = "shear_flow", ("continuity", "x_momentum", "y_momentum", "tracer")
+    GUARDED, PER_T, PER_T_FLAG = ("x_momentum", "y_momentum", "tracer"), "helper", "has_per_t_scales"
+    DEFAULT_EQ_SCALES = {"continuity": 1.0, "x_momentum": 1.0, "y_momentum": 1.0, "tracer": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 512, Lx: float = 1.0, Ly: float = 2.0, dt: float = 0.1,
+                 nu: float = 1e-4, D: float = 1e-3, use_div_correction: bool = True, eq_scales=None, eq_weights=None,
+                 eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.nu, self.D = Lx / nx, Ly / ny, dt, nu, D
+        self.use_div_correction = use_div_correction
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, nu=self.nu, D=self.D, div_corr=1.0 if self.use_div_correction else 0.0)
+
+    def forward(self, u: Tensor, v: Tensor, p: Tensor, s: Tensor, reduction: str = "mean", t_offset: Optional[Tensor] = None):
+        return self._evaluate([u, v, p, s], t_offset=t_offset)
+
+
+class Burgers2DCHPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:2079-2362"""
+    SPEC, EQS = "burgers2d_ch", ("u_momentum", "v_momentum", "irrotational")
+    GUARDED, PER_T, PER_T_FLAG = ("u_momentum", "v_momentum", "irrotational"), "helper", "has_per_t_scales"
+    DEFAULT_EQ_SCALES = {"u_momentum": 1.0, "v_momentum": 1.0, "irrotational": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 256, Lx: float = 6.283185307179586, Ly: float = 6.283185307179586,
+                 dt: float = 0.01, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt = Lx / nx, Ly / ny, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def _fixed_scale(self, eq):
+        s = float(self.eq_scales[eq])
+        if eq == "irrotational" and s < 1e-10:      # :2350-2356
+            return 1.0
+        return s
+
+    def forward(self, u: Tensor, v: Tensor, nu: Tensor, reduction: str = "mean", t_offset: Optional[Tensor] = None):
+        return self._evaluate([u, v], [self._sample_param(nu, None, u.shape[0], u)], t_offset=t_offset)
+
+
+class ActiveMatterNPINNPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:525-742 (the Dxx equation never uses per-timestep scales, :736-737)"""
+    SPEC, EQS = "active_matter", ("continuity", "concentration", "Dxx")
+    GUARDED, PER_T, PER_T_EQS = ("concentration", "Dxx"), "slice", ("continuity", "concentration")
+    DEFAULT_EQ_SCALES = {"continuity": 1.0, "concentration": 1.0, "Dxx": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 256, Lx: float = 10.0, Ly: float = 10.0, dt: float = 0.25,
+                 d_T: float = 0.05, use_div_correction: bool = True, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.d_T = Lx / nx, Ly / ny, dt, d_T
+        self.use_div_correction = use_div_correction
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, d_T=self.d_T, div_corr=1.0 if self.use_div_correction else 0.0)
+
+    def forward(self, u: Tensor, v: Tensor, c: Tensor, Dxx: Tensor):
+        return self._evaluate([u, v, c, Dxx])
+
+
+# =================================================================================================
+# 2-D mixed periodic / wall
+# =================================================================================================
+class RayleighBenardFullPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:749-1001 (fields [B, T, Nx, Ny]: dim -2 periodic, dim -1 between walls)"""
+    SPEC, EQS = "rayleigh_benard", ("continuity", "buoyancy")
+    GUARDED, PER_T, PER_T_FLAG = ("buoyancy",), "helper", "has_per_t_scales"
+    DEFAULT_EQ_SCALES = {"continuity": 1.0, "buoyancy": 1.0}
+
+    def __init__(self, nx: int = 512, ny: int = 128, Lx: float = 4.0, Ly: float = 1.0, dt: float = 0.25,
+                 kappa: float = 1e-5, skip_bl: int = 15, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.kappa, self.skip_bl = Lx / nx, Ly / (ny - 1), dt, kappa, skip_bl
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def _lattice(self, spatial):
+        sk = max(int(self.skip_bl), 0)
+        return (0, 0, sk), (0, 0, sk)
+
+    def forward(self, u: Tensor, v: Tensor, b: Tensor, kappa: Optional[Tensor] = None, t_offset: Optional[Tensor] = None):
+        return self._evaluate([u, v, b], [self._sample_param(kappa, self.kappa, u.shape[0], u)], t_offset=t_offset)
+
+
+class TurbulentRadiativePDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:1008-1139"""
+    SPEC, EQS = "turbulent_radiative", ("mass", "x_momentum", "y_momentum")
+    DEFAULT_EQ_SCALES = {"mass": 1.0, "x_momentum": 1.0, "y_momentum": 1.0}
+
+    def __init__(self, nx: int = 128, ny: int = 384, Lx: float = 1.0, Ly: float = 3.0, dt: float = 1.597033,
+                 skip_bl: int = 10, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.skip_bl = Lx / nx, Ly / (ny - 1), dt, skip_bl
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def _lattice(self, spatial):
+        sk = 1 + max(int(self.skip_bl), 0)
+        return (0, 0, sk), (0, 0, sk)
+
+    def forward(self, vx: Tensor, vy: Tensor, rho: Tensor, P: Tensor):
+        return self._evaluate([vx, vy, rho, P])
+
+
+class WaveGaussPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:1477-1569 (wave speed c is data: it receives no gradient)"""
+    SPEC, EQS, TOTAL_KEY = "wave_gauss", ("wave",), True
+    DEFAULT_EQ_SCALES = {"wave": 1.0}
+
+    def __init__(self, nx: int = 128, ny: int = 128, Lx: float = 1.0, Ly: float = 1.0, dt: float = 1.0 / 14,
+                 skip_boundary: int = 2, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.skip_boundary = Lx / nx, Ly / ny, dt, skip_boundary
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt)
+
+    def _lattice(self, spatial):
+        sb = 1 + max(int(self.skip_boundary), 0)
+        return (0, sb, sb), (0, sb, sb)
+
+    def forward(self, u: Tensor, c: Tensor):
+        if c.dim() == 4:
+            c = c[:, 0]
+        return self._evaluate([u], aux=[c])
+
+
+# =================================================================================================
+# Gray-Scott
+# =================================================================================================
+class GrayScottPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:148-302.
+
+    laplacian='fft' (default) reproduces the reference: spectral Laplacian (torch.fft -> rocFFT) feeding a
+    fused pointwise residual + reduction kernel.  laplacian='fd4' is the 4th-order periodic stencil of
+    tools/test_gt_pde_gray_scott.py:27-79 fused into one kernel (no FFT); it is a different discretisation
+    and agrees with the reference only on band-limited fields.
+
+    The reference reads its fixed scales and weights under the keys 'A' / 'B' (:161-164, :271, :283-288)
+    while the per-timestep buffers are named '*_equation' (:266-280); both conventions are kept.
+    """
+    EQS, PER_T, TOTAL_KEY = ("A_equation", "B_equation"), "slice", True
+    SCALE_KEYS = {"A_equation": "A", "B_equation": "B"}
+    DEFAULT_EQ_SCALES = {"A": 1.0, "B": 1.0}
+
+    def __init__(self, nx: int = 128, ny: int = 128, dx: float = 2.0 / 128, dy: float = 2.0 / 128, dt: float = 10.0,
+                 F: float = 0.098, k: float = 0.057, D_A: float = 1.81e-5, D_B: float = 1.39e-5, eq_scales=None,
+                 eq_weights=None, eq_scales_per_t=None, laplacian: str = "fft"):
+        super().__init__()
+        if laplacian not in ("fft", "fd4"):
+            raise ValueError("laplacian must be 'fft' or 'fd4'")
+        self.laplacian = laplacian
+        self.SPEC = "gray_scott_pw" if laplacian == "fft" else "gray_scott_fd"
+        self.nx, self.ny, self.dx, self.dy, self.dt = nx, ny, dx, dy, dt
+        self.F, self.k, self.D_A, self.D_B = F, k, D_A, D_B
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+        kx = torch.fft.fftfreq(nx, d=dx) * 2 * np.pi
+        ky = torch.fft.fftfreq(ny, d=dy) * 2 * np.pi
+        KX, KY = torch.meshgrid(kx, ky, indexing="ij")
+        self.register_buffer("K2", KX ** 2 + KY ** 2)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, F=self.F, k=self.k, D_A=self.D_A, D_B=self.D_B)
+
+    def fft_laplacian(self, f: Tensor) -> Tensor:
+        K2 = self.K2.to(f.device)
+        return torch.fft.ifft2(-K2 * torch.fft.fft2(f)).real
+
+    def forward(self, A: Tensor, B: Tensor, reduction: str = "mean"):
+        if reduction != "mean":
+            raise NotImplementedError("only reduction='mean' runs on the fused kernels")
+        if A.dim() == 3:
+            A, B = A.unsqueeze(0), B.unsqueeze(0)
+        if self.laplacian == "fd4":
+            return self._evaluate([A, B])
+        return self._evaluate([A, B, self.fft_laplacian(A), self.fft_laplacian(B)])
+
+
+# =================================================================================================
+# 3-D periodic
+# =================================================================================================
+class Advection3DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:2796-2917"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "advection3d", ("advection",), "slice", True
+    DEFAULT_EQ_SCALES = {"advection": 1.0}
+
+    def __init__(self, dx: float = 2 * np.pi / 64, dy: float = 2 * np.pi / 64, dz: float = 2 * np.pi / 64,
+                 dt: float = 0.05, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dy, self.dz, self.dt = dx, dy, dz, dt
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dz=self.dz, dt=self.dt)
+
+    def forward(self, u: Tensor, a: Tensor, b: Tensor, c: Tensor):
+        B = u.shape[0]
+        return self._evaluate([u], [self._sample_param(x, None, B, u) for x in (a, b, c)])
+
+
+class APEBenchBurgers3DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3426-3528"""
+    SPEC, EQS = "ape_burgers3d", ("u_momentum", "v_momentum", "w_momentum")
+    DEFAULT_EQ_SCALES = {"u_momentum": 1.0, "v_momentum": 1.0, "w_momentum": 1.0}
+
+    def __init__(self, nx: int = 32, Lx: float = 1.0, dt: float = 1.0, alpha_2: float = 2.4414e-4,
+                 beta_1: float = 1.5625e-2, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.dx, self.dt, self.alpha_2, self.beta_1 = Lx / nx, dt, alpha_2, beta_1
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt, alpha_2=self.alpha_2, beta_1=self.beta_1)
+
+    def forward(self, u: Tensor, v: Tensor, w: Tensor):
+        return self._evaluate([u, v, w])
+
+
+class SwiftHohenberg3DPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:3782-3876"""
+    SPEC, EQS, PER_T, TOTAL_KEY = "swift_hohenberg3d", ("swift_hohenberg",), "slice", True
+    DEFAULT_EQ_SCALES = {"swift_hohenberg": 1.0}
+
+    def __init__(self, domain_extent: float = 31.41592653589793, num_points: int = 32, dt: float = 0.1,
+                 reactivity: float = 0.7, critical_number: float = 1.0, eq_scales=None, eq_weights=None,
+                 eq_scales_per_t=None):
+        super().__init__()
+        self.dx, self.dt = domain_extent / num_points, dt
+        self.r, self.k = reactivity, critical_number
+        self.linear_coeff = reactivity - critical_number ** 2
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dt=self.dt, linear_coeff=self.linear_coeff, k=self.k)
+
+    def forward(self, u: Tensor):
+        return self._evaluate([u])
+
+
+class Heat3DPDELoss(StencilPDELoss):
+    """3-D heat equation u_t = alpha (u_xx + u_yy + u_zz), periodic, per-sample alpha.
+
+    The reference snapshot imports this class (finetune/train_heat_3d_lora_v3.py:69, constructed at :322-331,
+    called at :170) but does not define it.  The arithmetic follows the in-tree verifier
+    `verify_3d_heat` (finetune/generate_analytical_3d.py:160-178): 7-point 2nd-order Laplacian, central time
+    difference, mean of squares; dict keys follow Heat1DPDELoss (:3229).  No reference class pins it.
+    """
+    SPEC, EQS, PER_T, TOTAL_KEY = "heat3d", ("heat",), "slice", True
+    DEFAULT_EQ_SCALES = {"heat": 1.0}
+
+    def __init__(self, nx: int = 128, ny: int = 128, nz: int = 128, Lx: float = 2 * np.pi, Ly: float = 2 * np.pi,
+                 Lz: float = 2 * np.pi, dt: float = 0.01, alpha: float = 0.01, eq_scales=None, eq_weights=None,
+                 eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.dx, self.dy, self.dz, self.dt, self.alpha = Lx / nx, Ly / ny, Lz / nz, dt, alpha
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dz=self.dz, dt=self.dt)
+
+    def forward(self, u: Tensor, alpha: Optional[Tensor] = None):
+        return self._evaluate([u], [self._sample_param(alpha, self.alpha, u.shape[0], u)])
+
+
+# =================================================================================================
+# ghost-cell Burgers (finetune/pde_loss.py)
+# =================================================================================================
+def burgers_pde_loss(pred: Tensor, nu: float, dt: float = 1 / 999, dx: float = 1 / 127, dy: float = 1 / 127):
+    """finetune/pde_loss.py:87-216 — returns (total, loss_u, loss_v, residual_u, residual_v).
+
+    pred is channel-last [B, T, H, W, 2]; residuals are [B, T-1, H-2, W-2] (detached: they are diagnostics).
+    """
+    from .functional import _BACKEND  # late: tests may swap it
+    B, T, H, W, C2 = pred.shape
+    assert T >= 2, "T must be at least 2"
+    assert H >= 4 and W >= 4, "H, W must be at least 4"
+    u, v = pred[..., 0], pred[..., 1]
+    spec = SPECS["burgers2d_ghost"]
+    p = dict(nu=float(nu), dt=dt, dx=dx, dy=dy)
+    prob = StencilProblem("burgers2d_ghost", [fn(p) for _, fn in spec.consts], (0, 1, 1), (0, 1, 1))
+    n = B * (T - 1) * (H - 2) * (W - 2)
+    wt = torch.full((2, T - 1), 1.0 / n, dtype=torch.float32, device=pred.device)
+    sums = residual_sums(prob, [u, v], wt, mode="stored")
+    per_eq = sums.sum(dim=0).to(torch.float32)
+    loss_u, loss_v = per_eq[0], per_eq[1]
+    with torch.no_grad():
+        fs = [u.detach().float().contiguous(), v.detach().float().contiguous()]
+        _, resid = _BACKEND.forward(prob, fs, (), (), wt, True)
+    ru, rv = (r[:, :, 1:H - 1, 1:W - 1] for r in resid)
+    return loss_u + loss_v, loss_u, loss_v, ru, rv
+
+
+burgers_pde_loss_upwind = burgers_pde_loss

@@ -1,0 +1,492 @@
+"""Tiny symbolic engine for finite-difference residuals on a structured grid.
+
+A residual is an expression tree over *relative* grid references.  The engine
+differentiates a residual with respect to each referenced grid value and
+re-centres the derivative so that a *gather* adjoint stencil can be emitted:
+
+    grad_f(q) = sum_k sum_{refs r=(f,ot,o) of R_k}  G_k(q - o, t - ot) * dR_k/dr |_(q - o, t - ot)
+
+Nodes
+-----
+Num(v)                 literal
+Par(kind, i, name)     runtime scalar: kind 'c' per-instance constant, 's' per-sample parameter
+Ref(f, ot, o)          field f at time offset ot and spatial offset o=(o0,o1,o2) (tensor dims -3,-2,-1)
+Aux(a, o)              time-independent auxiliary field a at spatial offset o (never differentiated)
+GRef(k, ot, o)         scaled residual G_k = coef_k * R_k at a relative site (adjoint expressions only)
+Add(terms), Mul(factors), Recip(e)
+Sel(c, a, b)           c >= 0 ? a : b      (derivative flows through the selected branch only)
+PSel(p, a, b)          position predicate p ? a : b, p = Pred(axis, k, hi): index == k  (hi: == N-1-k)
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Tuple
+
+O3 = Tuple[int, int, int]
+ZERO3: O3 = (0, 0, 0)
+
+
+def addo(a: O3, b: O3) -> O3:
+    return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+
+
+def nego(a: O3) -> O3:
+    return (-a[0], -a[1], -a[2])
+
+
+class E:
+    __slots__ = ("_key",)
+
+    def key(self):
+        raise NotImplementedError
+
+    def __hash__(self):
+        return hash(self.key())
+
+    def __eq__(self, other):
+        return isinstance(other, E) and self.key() == other.key()
+
+    # arithmetic sugar
+    def __add__(self, o):
+        return add(self, wrap(o))
+
+    def __radd__(self, o):
+        return add(wrap(o), self)
+
+    def __sub__(self, o):
+        return add(self, mul(Num(-1.0), wrap(o)))
+
+    def __rsub__(self, o):
+        return add(wrap(o), mul(Num(-1.0), self))
+
+    def __mul__(self, o):
+        return mul(self, wrap(o))
+
+    def __rmul__(self, o):
+        return mul(wrap(o), self)
+
+    def __neg__(self):
+        return mul(Num(-1.0), self)
+
+    def __truediv__(self, o):
+        o = wrap(o)
+        if isinstance(o, Num):
+            return mul(self, Num(1.0 / o.v))
+        return mul(self, recip(o))
+
+
+class Num(E):
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = float(v)
+
+    def key(self):
+        return ("n", self.v)
+
+
+class Par(E):
+    __slots__ = ("kind", "i", "name")
+
+    def __init__(self, kind: str, i: int, name: str):
+        self.kind, self.i, self.name = kind, i, name
+
+    def key(self):
+        return ("p", self.kind, self.i)
+
+
+class Ref(E):
+    __slots__ = ("f", "ot", "o")
+
+    def __init__(self, f: int, ot: int = 0, o: O3 = ZERO3):
+        self.f, self.ot, self.o = f, ot, tuple(o)
+
+    def key(self):
+        return ("r", self.f, self.ot, self.o)
+
+
+class Aux(E):
+    __slots__ = ("a", "o")
+
+    def __init__(self, a: int, o: O3 = ZERO3):
+        self.a, self.o = a, tuple(o)
+
+    def key(self):
+        return ("x", self.a, self.o)
+
+
+class GRef(E):
+    __slots__ = ("k", "ot", "o")
+
+    def __init__(self, k: int, ot: int, o: O3):
+        self.k, self.ot, self.o = k, ot, tuple(o)
+
+    def key(self):
+        return ("g", self.k, self.ot, self.o)
+
+
+class Add(E):
+    __slots__ = ("terms",)
+
+    def __init__(self, terms):
+        self.terms = tuple(terms)
+
+    def key(self):
+        return ("+",) + tuple(t.key() for t in self.terms)
+
+
+class Mul(E):
+    __slots__ = ("factors",)
+
+    def __init__(self, factors):
+        self.factors = tuple(factors)
+
+    def key(self):
+        return ("*",) + tuple(t.key() for t in self.factors)
+
+
+class Recip(E):
+    __slots__ = ("e",)
+
+    def __init__(self, e):
+        self.e = e
+
+    def key(self):
+        return ("1/", self.e.key())
+
+
+class Pred:
+    """index along `axis` equals k (hi=False) or N-1-k (hi=True)."""
+    __slots__ = ("axis", "k", "hi")
+
+    def __init__(self, axis: int, k: int, hi: bool = False):
+        self.axis, self.k, self.hi = axis, k, hi
+
+    def key(self):
+        return ("P", self.axis, self.k, self.hi)
+
+    def shifted(self, do: O3) -> "Pred":
+        # predicate held at site s = q + do; rewrite it for q
+        d = do[self.axis]
+        return Pred(self.axis, self.k + d if self.hi else self.k - d, self.hi)
+
+
+class Sel(E):
+    __slots__ = ("c", "a", "b")
+
+    def __init__(self, c, a, b):
+        self.c, self.a, self.b = c, a, b
+
+    def key(self):
+        return ("?", self.c.key(), self.a.key(), self.b.key())
+
+
+class PSel(E):
+    __slots__ = ("p", "a", "b")
+
+    def __init__(self, p: Pred, a, b):
+        self.p, self.a, self.b = p, a, b
+
+    def key(self):
+        return ("P?", self.p.key(), self.a.key(), self.b.key())
+
+
+ZERO = Num(0.0)
+ONE = Num(1.0)
+
+
+def wrap(x) -> E:
+    return x if isinstance(x, E) else Num(x)
+
+
+def is_zero(e: E) -> bool:
+    return isinstance(e, Num) and e.v == 0.0
+
+
+def add(*xs: E) -> E:
+    terms: List[E] = []
+    c = 0.0
+    for x in xs:
+        if isinstance(x, Add):
+            sub = x.terms
+        else:
+            sub = (x,)
+        for t in sub:
+            if isinstance(t, Num):
+                c += t.v
+            else:
+                terms.append(t)
+    if c != 0.0:
+        terms.append(Num(c))
+    if not terms:
+        return ZERO
+    if len(terms) == 1:
+        return terms[0]
+    return Add(terms)
+
+
+def mul(*xs: E) -> E:
+    facs: List[E] = []
+    c = 1.0
+    for x in xs:
+        sub = x.factors if isinstance(x, Mul) else (x,)
+        for t in sub:
+            if isinstance(t, Num):
+                c *= t.v
+            else:
+                facs.append(t)
+    if c == 0.0:
+        return ZERO
+    if not facs:
+        return Num(c)
+    if c != 1.0:
+        facs.insert(0, Num(c))
+    if len(facs) == 1:
+        return facs[0]
+    return Mul(facs)
+
+
+def recip(e: E) -> E:
+    if isinstance(e, Num):
+        return Num(1.0 / e.v)
+    return Recip(e)
+
+
+def sel(c: E, a: E, b: E) -> E:
+    a, b = wrap(a), wrap(b)
+    if a == b:
+        return a
+    return Sel(c, a, b)
+
+
+def psel(p: Pred, a: E, b: E) -> E:
+    a, b = wrap(a), wrap(b)
+    if a == b:
+        return a
+    return PSel(p, a, b)
+
+
+# ---------------------------------------------------------------------------
+# traversal
+# ---------------------------------------------------------------------------
+
+def children(e: E) -> Iterable[E]:
+    if isinstance(e, Add):
+        return e.terms
+    if isinstance(e, Mul):
+        return e.factors
+    if isinstance(e, Recip):
+        return (e.e,)
+    if isinstance(e, Sel):
+        return (e.c, e.a, e.b)
+    if isinstance(e, PSel):
+        return (e.a, e.b)
+    return ()
+
+
+def collect(e: E, cls, out=None, seen=None):
+    """All distinct nodes of type cls inside e (conditions included)."""
+    if out is None:
+        out, seen = {}, set()
+    k = e.key()
+    if k in seen:
+        return out
+    seen.add(k)
+    if isinstance(e, cls):
+        out[k] = e
+    for ch in children(e):
+        collect(ch, cls, out, seen)
+    return out
+
+
+def diff(e: E, r: Ref, memo=None) -> E:
+    """d e / d r, with no derivative through Sel conditions."""
+    if memo is None:
+        memo = {}
+    k = e.key()
+    if k in memo:
+        return memo[k]
+    if isinstance(e, Ref):
+        res = ONE if e == r else ZERO
+    elif isinstance(e, (Num, Par, Aux, GRef)):
+        res = ZERO
+    elif isinstance(e, Add):
+        res = add(*[diff(t, r, memo) for t in e.terms])
+    elif isinstance(e, Mul):
+        parts = []
+        for i, f in enumerate(e.factors):
+            d = diff(f, r, memo)
+            if is_zero(d):
+                continue
+            parts.append(mul(d, *[g for j, g in enumerate(e.factors) if j != i]))
+        res = add(*parts) if parts else ZERO
+    elif isinstance(e, Recip):
+        d = diff(e.e, r, memo)
+        res = ZERO if is_zero(d) else mul(Num(-1.0), e, e, d)
+    elif isinstance(e, Sel):
+        res = sel(e.c, diff(e.a, r, memo), diff(e.b, r, memo))
+    elif isinstance(e, PSel):
+        res = psel(e.p, diff(e.a, r, memo), diff(e.b, r, memo))
+    else:
+        raise TypeError(type(e))
+    memo[k] = res
+    return res
+
+
+def shift(e: E, dt: int, do: O3, memo=None) -> E:
+    """Re-express e (held at site s, time t) relative to q where s = q + do, t = tq + dt."""
+    if memo is None:
+        memo = {}
+    k = e.key()
+    if k in memo:
+        return memo[k]
+    if isinstance(e, Ref):
+        res = Ref(e.f, e.ot + dt, addo(e.o, do))
+    elif isinstance(e, Aux):
+        res = Aux(e.a, addo(e.o, do))
+    elif isinstance(e, GRef):
+        res = GRef(e.k, e.ot + dt, addo(e.o, do))
+    elif isinstance(e, (Num, Par)):
+        res = e
+    elif isinstance(e, Add):
+        res = add(*[shift(t, dt, do, memo) for t in e.terms])
+    elif isinstance(e, Mul):
+        res = mul(*[shift(t, dt, do, memo) for t in e.factors])
+    elif isinstance(e, Recip):
+        res = recip(shift(e.e, dt, do, memo))
+    elif isinstance(e, Sel):
+        res = sel(shift(e.c, dt, do, memo), shift(e.a, dt, do, memo), shift(e.b, dt, do, memo))
+    elif isinstance(e, PSel):
+        res = psel(e.p.shifted(do), shift(e.a, dt, do, memo), shift(e.b, dt, do, memo))
+    else:
+        raise TypeError(type(e))
+    memo[k] = res
+    return res
+
+
+def adjoint_exprs(residuals: List[E], nfields: int) -> List[E]:
+    """Gather-form adjoint: one expression per field, over GRef and Ref nodes relative to the output site."""
+    out: List[List[E]] = [[] for _ in range(nfields)]
+    for k, R in enumerate(residuals):
+        refs = collect(R, Ref)
+        for rk in sorted(refs):
+            r = refs[rk]
+            J = diff(R, r)
+            if is_zero(J):
+                continue
+            do = nego(r.o)
+            out[r.f].append(mul(GRef(k, -r.ot, do), shift(J, -r.ot, do)))
+    return [add(*ts) if ts else ZERO for ts in out]
+
+
+# ---------------------------------------------------------------------------
+# footprint analysis
+# ---------------------------------------------------------------------------
+
+def footprint(exprs: List[E], cls) -> Dict[str, object]:
+    """Per-axis max |offset| and time-offset range of nodes of type cls, split by ot==0 / ot!=0."""
+    h0 = [0, 0, 0]
+    ht = [0, 0, 0]
+    tmin, tmax = 0, 0
+    n = 0
+    for e in exprs:
+        for node in collect(e, cls).values():
+            n += 1
+            ot = getattr(node, "ot", 0)
+            tmin, tmax = min(tmin, ot), max(tmax, ot)
+            tgt = h0 if ot == 0 else ht
+            for a in range(3):
+                tgt[a] = max(tgt[a], abs(node.o[a]))
+    return {"h0": tuple(h0), "ht": tuple(ht), "tmin": tmin, "tmax": tmax, "count": n}
+
+
+# ---------------------------------------------------------------------------
+# C emission with common-subexpression temporaries
+# ---------------------------------------------------------------------------
+
+def _flt(v: float) -> str:
+    import numpy as np
+    f = float(np.float32(v))
+    s = repr(f)
+    if "e" in s or "E" in s:
+        return s + "f"
+    if "." not in s and "inf" not in s and "nan" not in s:
+        s += ".0"
+    return s + "f"
+
+
+class Emitter:
+    """Prints expressions as C with temporaries for shared non-trivial subtrees."""
+
+    def __init__(self, acc: str = "a"):
+        self.acc = acc
+        self.lines: List[str] = []
+        self.names: Dict[object, str] = {}
+        self.count: Dict[object, int] = {}
+
+    def _count(self, e: E):
+        k = e.key()
+        self.count[k] = self.count.get(k, 0) + 1
+        if self.count[k] == 1:
+            for ch in children(e):
+                self._count(ch)
+
+    def prepare(self, exprs: Iterable[E]):
+        for e in exprs:
+            self._count(e)
+
+    def _atom(self, e: E) -> str:
+        a = self.acc
+        if isinstance(e, Num):
+            return _flt(e.v)
+        if isinstance(e, Par):
+            return f"{a}.{'c' if e.kind == 'c' else 'sp'}({e.i})"
+        if isinstance(e, Ref):
+            return f"{a}.F({e.f},{e.ot},{e.o[0]},{e.o[1]},{e.o[2]})"
+        if isinstance(e, Aux):
+            return f"{a}.X({e.a},{e.o[0]},{e.o[1]},{e.o[2]})"
+        if isinstance(e, GRef):
+            return f"{a}.G({e.k},{e.ot},{e.o[0]},{e.o[1]},{e.o[2]})"
+        raise TypeError(type(e))
+
+    def expr(self, e: E) -> str:
+        k = e.key()
+        if k in self.names:
+            return self.names[k]
+        if isinstance(e, (Num, Par)):
+            return self._atom(e)
+        if isinstance(e, (Ref, Aux, GRef)):
+            s = self._atom(e)
+        elif isinstance(e, Add):
+            parts = []
+            for i, t in enumerate(e.terms):
+                neg = False
+                if isinstance(t, Mul) and isinstance(t.factors[0], Num) and t.factors[0].v < 0:
+                    neg = True
+                    t = mul(Num(-t.factors[0].v), *t.factors[1:])
+                elif isinstance(t, Num) and t.v < 0:
+                    neg = True
+                    t = Num(-t.v)
+                s_t = self.expr(t)
+                if i == 0:
+                    parts.append(("-" if neg else "") + s_t)
+                else:
+                    parts.append((" - " if neg else " + ") + s_t)
+            s = "(" + "".join(parts) + ")"
+        elif isinstance(e, Mul):
+            s = "(" + " * ".join(self.expr(t) for t in e.factors) + ")"
+        elif isinstance(e, Recip):
+            s = "(1.0f / " + self.expr(e.e) + ")"
+        elif isinstance(e, Sel):
+            s = f"(({self.expr(e.c)}) >= 0.0f ? {self.expr(e.a)} : {self.expr(e.b)})"
+        elif isinstance(e, PSel):
+            fn = "ath" if e.p.hi else "at"
+            s = f"({self.acc}.{fn}({e.p.axis},{e.p.k}) ? {self.expr(e.a)} : {self.expr(e.b)})"
+        else:
+            raise TypeError(type(e))
+        # loads and shared subtrees become named temporaries
+        if isinstance(e, (Ref, Aux, GRef)) or self.count.get(k, 0) > 1:
+            name = f"t{len(self.names)}"
+            self.lines.append(f"const float {name} = {s};")
+            self.names[k] = name
+            return name
+        return s

@@ -1,0 +1,159 @@
+"""Grid quantities: callables (ot, o) -> expression, closed under pointwise arithmetic and stencils.
+
+A quantity evaluated at (ot, o) is its value at the residual site shifted by time offset `ot` and
+spatial offset `o`; composing stencils (a derivative of a derivative, a derivative of a product)
+is plain function composition, so the expression engine only ever sees relative grid references.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Sequence
+
+from .expr import E, Num, Par, Pred, Ref, Aux, O3, ZERO3, add, addo, mul, psel, sel, wrap, recip
+
+
+class Q:
+    __slots__ = ("fn",)
+
+    def __init__(self, fn: Callable[[int, O3], E]):
+        self.fn = fn
+
+    def __call__(self, ot: int = 0, o: O3 = ZERO3) -> E:
+        return self.fn(ot, o)
+
+    @staticmethod
+    def lift(x) -> "Q":
+        if isinstance(x, Q):
+            return x
+        e = wrap(x)
+        return Q(lambda ot, o: e)
+
+    def __add__(self, other):
+        b = Q.lift(other)
+        return Q(lambda ot, o: add(self(ot, o), b(ot, o)))
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        b = Q.lift(other)
+        return Q(lambda ot, o: add(self(ot, o), mul(Num(-1.0), b(ot, o))))
+
+    def __rsub__(self, other):
+        b = Q.lift(other)
+        return Q(lambda ot, o: add(b(ot, o), mul(Num(-1.0), self(ot, o))))
+
+    def __mul__(self, other):
+        b = Q.lift(other)
+        return Q(lambda ot, o: mul(self(ot, o), b(ot, o)))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return Q(lambda ot, o: mul(Num(-1.0), self(ot, o)))
+
+    def __truediv__(self, other):
+        b = Q.lift(other)
+        return Q(lambda ot, o: mul(self(ot, o), recip(b(ot, o))))
+
+
+def field(i: int) -> Q:
+    return Q(lambda ot, o: Ref(i, ot, o))
+
+
+def aux(i: int) -> Q:
+    return Q(lambda ot, o: Aux(i, o))
+
+
+def const(i: int, name: str) -> Q:
+    p = Par("c", i, name)
+    return Q(lambda ot, o: p)
+
+
+def sparam(i: int, name: str) -> Q:
+    p = Par("s", i, name)
+    return Q(lambda ot, o: p)
+
+
+def _axis_off(axis: int, k: int) -> O3:
+    v = [0, 0, 0]
+    v[axis] = k
+    return tuple(v)
+
+
+def sh(q: Q, axis: int, k: int) -> Q:
+    """q displaced by k cells along `axis` (periodic wrap or halo fill is the loader's business)."""
+    d = _axis_off(axis, k)
+    return Q(lambda ot, o: q(ot, addo(o, d)))
+
+
+def tsh(q: Q, dt: int) -> Q:
+    return Q(lambda ot, o: q(ot + dt, o))
+
+
+def stencil(q: Q, axis: int, coefs: Dict[int, float], scale) -> Q:
+    """scale * sum_k coefs[k] * q[i + k] along `axis`."""
+    s = Q.lift(scale)
+    items = sorted(coefs.items(), key=lambda kv: -kv[0])
+
+    def fn(ot, o):
+        terms = [mul(Num(c), q(ot, addo(o, _axis_off(axis, k)))) for k, c in items]
+        return mul(s(ot, o), add(*terms))
+
+    return Q(fn)
+
+
+# central-difference coefficient tables (index offset -> weight), scaled by the caller
+C4_D1 = {2: -1.0, 1: 8.0, -1: -8.0, -2: 1.0}            # / (12 h)
+C4_D2 = {2: -1.0, 1: 16.0, 0: -30.0, -1: 16.0, -2: -1.0}  # / (12 h^2)
+C2_D1 = {1: 1.0, -1: -1.0}                               # / (2 h)
+C2_D2 = {1: 1.0, 0: -2.0, -1: 1.0}                       # / h^2
+D4_5PT = {2: 1.0, 1: -4.0, 0: 6.0, -1: -4.0, -2: 1.0}    # / h^4
+KDV_D3 = {3: -1.0 / 8, 2: 1.0, 1: -13.0 / 8, -1: 13.0 / 8, -2: -1.0, -3: 1.0 / 8}       # / h^3
+KDV_D4 = {3: -1.0 / 6, 2: 2.0, 1: -13.0 / 2, 0: 28.0 / 3, -1: -13.0 / 2, -2: 2.0, -3: -1.0 / 6}  # / h^4
+
+
+def qsel(c: Q, a: Q, b: Q) -> Q:
+    a, b = Q.lift(a), Q.lift(b)
+    return Q(lambda ot, o: sel(c(ot, o), a(ot, o), b(ot, o)))
+
+
+def qpsel(axis: int, k: int, hi: bool, a, b) -> Q:
+    """Position test at the site where the quantity is evaluated: index == k (or N-1-k when hi)."""
+    a, b = Q.lift(a), Q.lift(b)
+
+    def fn(ot, o):
+        # the quantity is evaluated at residual site + o, so the test on that site's index
+        # becomes a test on the residual site's index displaced by -o
+        p = Pred(axis, k, hi).shifted(o)
+        return psel(p, a(ot, o), b(ot, o))
+
+    return Q(fn)
+
+
+def dt_central(q: Q, inv2dt) -> Q:
+    """(q[t+1] - q[t-1]) * inv2dt"""
+    return (tsh(q, 1) - tsh(q, -1)) * Q.lift(inv2dt)
+
+
+def upwind_flux_div(f: Q, u: Q, v: Q, ax_x: int, ax_y: int, inv_dx, inv_dy) -> Q:
+    """Conservative 2nd-order upwind convection div(f * (u, v)) on face-averaged velocities.
+
+    East face of cell i carries velocity 0.5*(u[i] + u[i+1]) and the face value
+    1.5 f[i] - 0.5 f[i-1] when that velocity is >= 0, else 1.5 f[i+1] - 0.5 f[i+2];
+    the west face of cell i is the east face of cell i-1.
+    """
+    def face_flux(vel: Q, axis: int) -> Q:
+        vc = 0.5 * (vel + sh(vel, axis, 1))
+        pos = 1.5 * f - 0.5 * sh(f, axis, -1)
+        neg = 1.5 * sh(f, axis, 1) - 0.5 * sh(f, axis, 2)
+        return vc * qsel(vc, pos, neg)
+
+    fx = face_flux(u, ax_x)
+    fy = face_flux(v, ax_y)
+    return (fx - sh(fx, ax_x, -1)) * Q.lift(inv_dx) + (fy - sh(fy, ax_y, -1)) * Q.lift(inv_dy)
+
+
+def face_div(u: Q, v: Q, ax_x: int, ax_y: int, inv_dx, inv_dy) -> Q:
+    """(uc_e - uc_w)/dx + (vc_n - vc_s)/dy with face velocities 0.5*(w[i] + w[i±1])."""
+    ue = 0.5 * (u + sh(u, ax_x, 1))
+    vn = 0.5 * (v + sh(v, ax_y, 1))
+    return (ue - sh(ue, ax_x, -1)) * Q.lift(inv_dx) + (vn - sh(vn, ax_y, -1)) * Q.lift(inv_dy)

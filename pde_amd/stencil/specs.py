@@ -1,0 +1,452 @@
+"""Residual definitions of every supported PDE loss, as symbolic stencil expressions.
+
+Axis numbering follows tensor dims: axis 0/1/2 = dim -3/-2/-1 of a field [B, T, (D0,) D1, D2].
+Which axis a class calls "x" differs per class in the reference and is repeated here per spec.
+Every citation is a line range of finetune/pde_loss_verified.py in the reference tree unless a
+different file is named.
+
+Per-instance constants are folded on the host in double precision and rounded once to fp32
+(the reference divides fp32 tensors by Python doubles, which differs by at most 1 ulp per stencil).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field as dc_field
+from typing import Callable, Dict, List, Sequence, Tuple
+
+from .expr import E, Ref, GRef, adjoint_exprs, footprint
+from .ops import (Q, C2_D1, C2_D2, C4_D1, C4_D2, D4_5PT, KDV_D3, KDV_D4, aux, const, dt_central,
+                  face_div, field, qpsel, qsel, sh, sparam, stencil, tsh, upwind_flux_div)
+
+ConstFn = Callable[[Dict[str, float]], float]
+
+
+@dataclass
+class Spec:
+    name: str
+    ndim: int
+    fields: List[str]
+    eqs: List[str]
+    consts: List[Tuple[str, ConstFn]]
+    sparams: List[str]
+    periodic: Tuple[bool, bool, bool]      # per axis 0,1,2 (unused leading axes: True)
+    residuals: List[E]
+    aux: List[str] = dc_field(default_factory=list)
+    doc: str = ""
+    # tile shapes (axis0, axis1, axis2) and threads for the kernels
+    tile_fwd: Tuple[int, int, int] = (1, 16, 64)
+    tile_bwd: Tuple[int, int, int] = (1, 16, 64)
+    threads: int = 256
+
+    # derived
+    def analyse(self):
+        nf = len(self.fields)
+        self.adjoint = adjoint_exprs(self.residuals, nf)
+        self.fp_res = footprint(self.residuals, Ref)
+        self.fp_adj_f = footprint(self.adjoint, Ref)
+        self.fp_adj_g = footprint(self.adjoint, GRef)
+        self.tlo = -self.fp_res["tmin"]
+        self.thi = self.fp_res["tmax"]
+        return self
+
+
+class _B:
+    """Spec builder: hands out fields / constants / per-sample parameters as quantities."""
+
+    def __init__(self, name, ndim, fields, eqs, periodic=(True, True, True), aux_names=(), doc=""):
+        self.name, self.ndim, self.fields, self.eqs = name, ndim, list(fields), list(eqs)
+        self.periodic, self.doc = periodic, doc
+        self.consts: List[Tuple[str, ConstFn]] = []
+        self.sparams: List[str] = []
+        self.aux_names = list(aux_names)
+
+    def F(self):
+        qs = [field(i) for i in range(len(self.fields))]
+        return qs[0] if len(qs) == 1 else qs
+
+    def A(self, i=0):
+        return aux(i)
+
+    def c(self, name: str, fn: ConstFn) -> Q:
+        for i, (n, _) in enumerate(self.consts):
+            if n == name:
+                return const(i, name)
+        self.consts.append((name, fn))
+        return const(len(self.consts) - 1, name)
+
+    def s(self, name: str) -> Q:
+        self.sparams.append(name)
+        return sparam(len(self.sparams) - 1, name)
+
+    def done(self, residuals: Sequence[Q], **kw) -> Spec:
+        res = [r(0, (0, 0, 0)) for r in residuals]
+        assert len(res) == len(self.eqs)
+        return Spec(self.name, self.ndim, self.fields, self.eqs, self.consts, self.sparams,
+                    self.periodic, res, aux=self.aux_names, doc=self.doc, **kw).analyse()
+
+
+# ---- constant formulas -------------------------------------------------------------------------
+def _inv2dt(p): return 1.0 / (2.0 * p["dt"])
+def _k(name): return lambda p: float(p[name])
+def _inv12(h): return lambda p: 1.0 / (12.0 * p[h])
+def _inv12sq(h): return lambda p: 1.0 / (12.0 * p[h] ** 2)
+def _inv(h, n=1): return lambda p: 1.0 / (p[h] ** n)
+def _inv2(h): return lambda p: 1.0 / (2.0 * p[h])
+
+
+def _d1c4(b, q, axis, h): return stencil(q, axis, C4_D1, b.c("inv12" + h, _inv12(h)))
+def _d2c4(b, q, axis, h): return stencil(q, axis, C4_D2, b.c("inv12" + h + "2", _inv12sq(h)))
+def _d2c2(b, q, axis, h): return stencil(q, axis, C2_D2, b.c("inv_" + h + "2", _inv(h, 2)))
+def _d1c2(b, q, axis, h): return stencil(q, axis, C2_D1, b.c("inv2" + h, _inv2(h)))
+def _ddt(b, q): return dt_central(q, b.c("inv2dt", _inv2dt))
+
+
+SPECS: Dict[str, Spec] = {}
+
+
+def _reg(s: Spec):
+    SPECS[s.name] = s
+    return s
+
+
+T1D = dict(tile_fwd=(1, 1, 256), tile_bwd=(1, 1, 256), threads=256)
+T3D = dict(tile_fwd=(2, 4, 64), tile_bwd=(4, 8, 64), threads=256)
+
+
+# ---- 1-D periodic family -----------------------------------------------------------------------
+def _burgers1d():
+    # Burgers1DPDELoss :2924-3027 — R = u_t + u u_x - nu u_xx, c4 periodic on dim -1
+    b = _B("burgers1d", 1, ["u"], ["momentum"])
+    u = b.F()
+    nu = b.s("nu")
+    return b.done([_ddt(b, u) + u * _d1c4(b, u, 2, "dx") - nu * _d2c4(b, u, 2, "dx")], **T1D)
+
+
+def _advection1d():
+    # Advection1DPDELoss :3034-3127 — R = u_t + a u_x
+    b = _B("advection1d", 1, ["u"], ["advection"])
+    u = b.F()
+    a = b.s("a")
+    return b.done([_ddt(b, u) + a * _d1c4(b, u, 2, "dx")], **T1D)
+
+
+def _heat1d():
+    # Heat1DPDELoss :3134-3229 — R = u_t - alpha u_xx
+    b = _B("heat1d", 1, ["u"], ["heat"])
+    u = b.F()
+    al = b.s("alpha")
+    return b.done([_ddt(b, u) - al * _d2c4(b, u, 2, "dx")], **T1D)
+
+
+def _ape_burgers1d():
+    # APEBenchBurgers1DPDELoss :3348-3419 — R = u_t - alpha_2 u_xx(c2) - delta u u_x(c4)
+    b = _B("ape_burgers1d", 1, ["u"], ["momentum"])
+    u = b.F()
+    a2, dl = b.c("alpha_2", _k("alpha_2")), b.c("delta_conv", _k("delta_conv"))
+    return b.done([_ddt(b, u) - a2 * _d2c2(b, u, 2, "dx") - dl * u * _d1c4(b, u, 2, "dx")], **T1D)
+
+
+def _ks1d():
+    # KS1DPDELoss :3535-3649 — R = u_t - a2 u_xx(c4) - a4 u_xxxx(5pt) - b2 * 0.5 * u_x^2
+    b = _B("ks1d", 1, ["u"], ["momentum"])
+    u = b.F()
+    a2, a4, b2 = b.c("alpha_2", _k("alpha_2")), b.c("alpha_4", _k("alpha_4")), b.c("beta_2", _k("beta_2"))
+    ux = _d1c4(b, u, 2, "dx")
+    d4 = stencil(u, 2, D4_5PT, b.c("inv_dx4", _inv("dx", 4)))
+    return b.done([_ddt(b, u) - a2 * _d2c4(b, u, 2, "dx") - a4 * d4 - b2 * (0.5 * ux * ux)], **T1D)
+
+
+def _kdv1d():
+    # KdV1DPDELoss :3656-3775 — R = u_t - b1 u u_x - a3 u_xxx - a4 u_xxxx (7-point d3, d4)
+    b = _B("kdv1d", 1, ["u"], ["kdv"])
+    u = b.F()
+    a3, a4, b1 = b.c("alpha_3", _k("alpha_3")), b.c("alpha_4", _k("alpha_4")), b.c("beta_1", _k("beta_1"))
+    d3 = stencil(u, 2, KDV_D3, b.c("inv_dx3", _inv("dx", 3)))
+    d4 = stencil(u, 2, KDV_D4, b.c("inv_dx4", _inv("dx", 4)))
+    return b.done([_ddt(b, u) - b1 * u * _d1c4(b, u, 2, "dx") - a3 * d3 - a4 * d4], **T1D)
+
+
+# ---- 2-D periodic central family ---------------------------------------------------------------
+def _tg2d():
+    # TaylorGreen2DPDELoss :1717-1923 — x along dim -1 (dx), y along dim -2 (dy), c4, per-sample nu
+    b = _B("tg2d", 2, ["u", "v", "p"], ["continuity", "x_momentum", "y_momentum"])
+    u, v, p = b.F()
+    nu = b.s("nu")
+    dx = lambda q: _d1c4(b, q, 2, "dx")
+    dy = lambda q: _d1c4(b, q, 1, "dy")
+    lap = lambda q: _d2c4(b, q, 2, "dx") + _d2c4(b, q, 1, "dy")
+    cont = dx(u) + dy(v)
+    xm = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - nu * lap(u)
+    ym = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - nu * lap(v)
+    return b.done([cont, xm, ym])
+
+
+def _advdiff2d():
+    # AdvDiff2DPDELoss :2369-2495 — R = u_t + a u_x + b u_y - nu lap4(u); x dim -1, y dim -2
+    b = _B("advdiff2d", 2, ["u"], ["advdiff"])
+    u = b.F()
+    a, bb, nu = b.c("a", _k("a")), b.c("b", _k("b")), b.c("nu", _k("nu"))
+    lap = _d2c4(b, u, 2, "dx") + _d2c4(b, u, 1, "dy")
+    return b.done([_ddt(b, u) + a * _d1c4(b, u, 2, "dx") + bb * _d1c4(b, u, 1, "dy") - nu * lap])
+
+
+def _anisodiff2d():
+    # AnisoDiff2DPDELoss :2502-2643 — u_xy = d_y(d_x u), chained c4
+    b = _B("anisodiff2d", 2, ["u"], ["aniso_diff"])
+    u = b.F()
+    axx, axy, ayy = b.c("A_xx", _k("A_xx")), b.c("A_xy_sum", lambda p: p["A_xy"] + p["A_yx"]), b.c("A_yy", _k("A_yy"))
+    uxy = _d1c4(b, _d1c4(b, u, 2, "dx"), 1, "dy")
+    return b.done([_ddt(b, u) - axx * _d2c4(b, u, 2, "dx") - axy * uxy - ayy * _d2c4(b, u, 1, "dy")])
+
+
+def _wave2d():
+    # Wave2DPDELoss :2650-2789 — R_u = u_t - w ; R_w = w_t - c^2 lap4(u); x dim -2 (dx), y dim -1 (dy)
+    b = _B("wave2d", 2, ["u", "w"], ["u_equation", "w_equation"])
+    u, w = b.F()
+    c2 = b.s("c2")
+    lap = _d2c4(b, u, 1, "dx") + _d2c4(b, u, 2, "dy")
+    return b.done([_ddt(b, u) - w, _ddt(b, w) - c2 * lap])
+
+
+def _ape_burgers2d():
+    # APEBenchBurgers2DPDELoss :3241-3341 — c4 gradients, c2 Laplacian; x dim -1, y dim -2
+    b = _B("ape_burgers2d", 2, ["u", "v"], ["u_momentum", "v_momentum"])
+    u, v = b.F()
+    a2, dl = b.c("alpha_2", _k("alpha_2")), b.c("delta_conv", _k("delta_conv"))
+    dx = lambda q: _d1c4(b, q, 2, "dx")
+    dy = lambda q: _d1c4(b, q, 1, "dy")
+    lap = lambda q: _d2c2(b, q, 2, "dx") + _d2c2(b, q, 1, "dy")
+    ru = _ddt(b, u) - a2 * lap(u) - dl * (u * dx(u) + v * dy(u))
+    rv = _ddt(b, v) - a2 * lap(v) - dl * (u * dx(v) + v * dy(v))
+    return b.done([ru, rv])
+
+
+def _nspwc():
+    # NSPwCPDELoss :1576-1710 — c2; vorticity w = v_x - u_y built at t-1, t, t+1; x dim -1, y dim -2
+    b = _B("nspwc", 2, ["u", "v", "s"], ["divergence", "vorticity", "tracer"])
+    u, v, s = b.F()
+    nu, ka = b.c("nu", _k("nu")), b.c("kappa", _k("kappa"))
+    dx = lambda q: _d1c2(b, q, 2, "dx")
+    dy = lambda q: _d1c2(b, q, 1, "dy")
+    lap = lambda q: _d2c2(b, q, 2, "dx") + _d2c2(b, q, 1, "dy")
+    om = dx(v) - dy(u)
+    div = dx(u) + dy(v)
+    vort = _ddt(b, om) + u * dx(om) + v * dy(om) - nu * lap(om)
+    trc = _ddt(b, s) + u * dx(s) + v * dy(s) - ka * lap(s)
+    return b.done([div, vort, trc], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+
+
+def _kp2d():
+    # KP2DPDELoss :1930-2072 — R = (u_x)_t + 6 u_x^2 + 6 u u_xx + u_xxxx + 3 u_yy; x dim -2, y dim -1;
+    # the crop `skip_boundary` is the runtime lattice
+    b = _B("kp2d", 2, ["u"], ["kp2_equation"])
+    u = b.F()
+    ux = _d1c4(b, u, 1, "dx")
+    d4 = stencil(u, 1, D4_5PT, b.c("inv_dx4", _inv("dx", 4)))
+    R = _ddt(b, ux) + 6.0 * ux * ux + 6.0 * u * _d2c4(b, u, 1, "dx") + d4 + 3.0 * _d2c4(b, u, 2, "dy")
+    return b.done([R], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+
+
+# ---- 2-D n-PINN upwind family ------------------------------------------------------------------
+def _npinn_parts(b, u, v, ax_x, ax_y):
+    idx, idy = b.c("inv_dx", _inv("dx")), b.c("inv_dy", _inv("dy"))
+    div = face_div(u, v, ax_x, ax_y, idx, idy)
+    conv = lambda f: upwind_flux_div(f, u, v, ax_x, ax_y, idx, idy)
+    lap = lambda f: _d2c2(b, f, ax_x, "dx") + _d2c2(b, f, ax_y, "dy")
+    return div, conv, lap
+
+
+def _shear_flow():
+    # ShearFlowPDELossNPINN :1146-1470 — x dim -2 (dx), y dim -1 (dy)
+    b = _B("shear_flow", 2, ["u", "v", "p", "s"], ["continuity", "x_momentum", "y_momentum", "tracer"])
+    u, v, p, s = b.F()
+    div, conv, lap = _npinn_parts(b, u, v, 1, 2)
+    nu, D, dc = b.c("nu", _k("nu")), b.c("D", _k("D")), b.c("div_corr", _k("div_corr"))
+    ru = _ddt(b, u) + conv(u) + _d1c2(b, p, 1, "dx") - nu * lap(u) - dc * u * div
+    rv = _ddt(b, v) + conv(v) + _d1c2(b, p, 2, "dy") - nu * lap(v) - dc * v * div
+    rs = _ddt(b, s) + conv(s) - D * lap(s) - dc * s * div
+    return b.done([div, ru, rv, rs], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+
+
+def _burgers2d_ch():
+    # Burgers2DCHPDELoss :2079-2362 — x dim -1, y dim -2; irrotational constraint with c4
+    b = _B("burgers2d_ch", 2, ["u", "v"], ["u_momentum", "v_momentum", "irrotational"])
+    u, v = b.F()
+    nu = b.s("nu")
+    div, conv, lap = _npinn_parts(b, u, v, 2, 1)
+    ru = _ddt(b, u) + conv(u) - u * div - nu * lap(u)
+    rv = _ddt(b, v) + conv(v) - v * div - nu * lap(v)
+    irr = _d1c4(b, v, 2, "dx") - _d1c4(b, u, 1, "dy")
+    return b.done([ru, rv, irr])
+
+
+def _active_matter():
+    # ActiveMatterNPINNPDELoss :525-742 — x dim -1, y dim -2
+    b = _B("active_matter", 2, ["u", "v", "c", "Dxx"], ["continuity", "concentration", "Dxx"])
+    u, v, c, dxx = b.F()
+    div, conv, lap = _npinn_parts(b, u, v, 2, 1)
+    dT, dc = b.c("d_T", _k("d_T")), b.c("div_corr", _k("div_corr"))
+    rc = _ddt(b, c) + conv(c) - dT * lap(c) - dc * c * div
+    rd = _ddt(b, dxx) + conv(dxx) - dT * lap(dxx) - dc * dxx * div
+    return b.done([div, rc, rd], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+
+
+# ---- 2-D mixed periodic / wall family ----------------------------------------------------------
+def _rayleigh_benard():
+    # RayleighBenardFullPDELoss :749-1001 — x dim -2 periodic c4; y dim -1 walls: c2 interior,
+    # one-sided first derivative and zero second derivative on the wall rows (:823-852);
+    # rows cropped by skip_bl = runtime lattice on axis 2
+    b = _B("rayleigh_benard", 2, ["u", "v", "b"], ["continuity", "buoyancy"], periodic=(True, True, False))
+    u, v, bb = b.F()
+    ka = b.s("kappa")
+    idy = b.c("inv_dy", _inv("dy"))
+
+    def dyg(q):
+        lo = (sh(q, 2, 1) - q) * idy
+        hi = (q - sh(q, 2, -1)) * idy
+        return qpsel(2, 0, False, lo, qpsel(2, 0, True, hi, _d1c2(b, q, 2, "dy")))
+
+    def d2yg(q):
+        return qpsel(2, 0, False, 0.0, qpsel(2, 0, True, 0.0, _d2c2(b, q, 2, "dy")))
+
+    cont = _d1c4(b, u, 1, "dx") + dyg(v)
+    buoy = _ddt(b, bb) + u * _d1c4(b, bb, 1, "dx") + v * dyg(bb) - ka * (_d2c4(b, bb, 1, "dx") + d2yg(bb))
+    return b.done([cont, buoy])
+
+
+def _turbulent_radiative():
+    # TurbulentRadiativePDELoss :1008-1139 — conservative Euler; x dim -2 periodic c4, y dim -1 open:
+    # c2 on interior rows only; lattice on axis 2 is [1+skip, N-1-skip)
+    b = _B("turbulent_radiative", 2, ["vx", "vy", "rho", "P"], ["mass", "x_momentum", "y_momentum"],
+           periodic=(True, True, False))
+    vx, vy, rho, P = b.F()
+    dx = lambda q: _d1c4(b, q, 1, "dx")
+    dy = lambda q: _d1c2(b, q, 2, "dy")
+    mass = _ddt(b, rho) + dx(rho * vx) + dy(rho * vy)
+    xm = _ddt(b, rho * vx) + dx(rho * vx * vx + P) + dy(rho * vx * vy)
+    ym = _ddt(b, rho * vy) + dx(rho * vx * vy) + dy(rho * vy * vy + P)
+    return b.done([mass, xm, ym], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+
+
+def _wave_gauss():
+    # WaveGaussPDELoss :1477-1569 — R = u_tt / c(x)^2 - lap2(u); both axes non-periodic;
+    # lattice [1+sb, N-1-sb) on both axes; c is a time-independent field
+    b = _B("wave_gauss", 2, ["u"], ["wave"], periodic=(True, False, False), aux_names=["c"])
+    u = b.F()
+    c = b.A(0)
+    utt = (tsh(u, 1) - 2.0 * u + tsh(u, -1)) * b.c("inv_dt2", _inv("dt", 2))
+    lap = _d2c2(b, u, 1, "dx") + _d2c2(b, u, 2, "dy")
+    return b.done([utt / (c * c) - lap])
+
+
+def _burgers2d_ghost():
+    # burgers_pde_loss, finetune/pde_loss.py:87-216 — non-conservative 2nd-order upwind on sign(u), sign(v);
+    # ghost cells 2 f[0] - f[1] beyond each wall (:125-135); backward time difference (:168-173);
+    # residual lattice [1, N-1) on both axes; x dim -1, y dim -2
+    b = _B("burgers2d_ghost", 2, ["u", "v"], ["u", "v"], periodic=(True, False, False))
+    u, v = b.F()
+    nu = b.c("nu", _k("nu"))
+    idt = b.c("inv_dt", _inv("dt"))
+    i2dx, i2dy = b.c("inv2dx", _inv2("dx")), b.c("inv2dy", _inv2("dy"))
+
+    def nb(q, axis, k):
+        """Neighbour k cells away along axis with the linear-extrapolation ghost one cell past a wall."""
+        if abs(k) < 2:
+            return sh(q, axis, k)
+        if k == -2:   # site index 1 reaches the low ghost: 2 f[0] - f[1]
+            return qpsel(axis, 1, False, 2.0 * sh(q, axis, -1) - q, sh(q, axis, -2))
+        return qpsel(axis, 1, True, 2.0 * sh(q, axis, 1) - q, sh(q, axis, 2))
+
+    def upw(phi, vel, axis, i2h):
+        back = (3.0 * phi - 4.0 * nb(phi, axis, -1) + nb(phi, axis, -2)) * i2h
+        fwd = (-3.0 * phi + 4.0 * nb(phi, axis, 1) - nb(phi, axis, 2)) * i2h
+        return qsel(vel, back, fwd)
+
+    lap = lambda q: _d2c2(b, q, 2, "dx") + _d2c2(b, q, 1, "dy")
+    ddt = lambda q: (q - tsh(q, -1)) * idt
+    ru = ddt(u) + u * upw(u, u, 2, i2dx) + v * upw(u, v, 1, i2dy) - nu * lap(u)
+    rv = ddt(v) + u * upw(v, u, 2, i2dx) + v * upw(v, v, 1, i2dy) - nu * lap(v)
+    return b.done([ru, rv])
+
+
+# ---- Gray-Scott ---------------------------------------------------------------------------------
+def _gray_scott_fd():
+    # c4 periodic Laplacian restatement, tools/test_gt_pde_gray_scott.py:27-79 (x = axis -2);
+    # reaction terms as GrayScottPDELoss :252-256
+    b = _B("gray_scott_fd", 2, ["A", "B"], ["A_equation", "B_equation"])
+    A, Bq = b.F()
+    DA, DB = b.c("D_A", _k("D_A")), b.c("D_B", _k("D_B"))
+    Fc, Fk = b.c("F", _k("F")), b.c("F_plus_k", lambda p: p["F"] + p["k"])
+    lap = lambda q: _d2c4(b, q, 1, "dx") + _d2c4(b, q, 2, "dy")
+    ab2 = A * Bq * Bq
+    ra = _ddt(b, A) - DA * lap(A) + ab2 - Fc * (1.0 - A)
+    rb = _ddt(b, Bq) - DB * lap(Bq) - ab2 + Fk * Bq
+    return b.done([ra, rb])
+
+
+def _gray_scott_pw():
+    # GrayScottPDELoss :216-302 with the spectral Laplacians supplied as two extra fields
+    # (computed by rocFFT through torch.fft): pointwise residual + reduction only
+    b = _B("gray_scott_pw", 2, ["A", "B", "lapA", "lapB"], ["A_equation", "B_equation"])
+    A, Bq, lA, lB = b.F()
+    DA, DB = b.c("D_A", _k("D_A")), b.c("D_B", _k("D_B"))
+    Fc, Fk = b.c("F", _k("F")), b.c("F_plus_k", lambda p: p["F"] + p["k"])
+    ab2 = A * Bq * Bq
+    ra = _ddt(b, A) - DA * lA + ab2 - Fc * (1.0 - A)
+    rb = _ddt(b, Bq) - DB * lB - ab2 + Fk * Bq
+    return b.done([ra, rb])
+
+
+# ---- 3-D periodic family ------------------------------------------------------------------------
+def _advection3d():
+    # Advection3DPDELoss :2796-2917 — x,y,z = dims -3,-2,-1; per-sample a,b,c
+    b = _B("advection3d", 3, ["u"], ["advection"])
+    u = b.F()
+    a, bb, c = b.s("a"), b.s("b"), b.s("c")
+    R = _ddt(b, u) + a * _d1c4(b, u, 0, "dx") + bb * _d1c4(b, u, 1, "dy") + c * _d1c4(b, u, 2, "dz")
+    return b.done([R], **T3D)
+
+
+def _ape_burgers3d():
+    # APEBenchBurgers3DPDELoss :3426-3528 — phi_t + beta_1 * 0.5 * div(phi (u,v,w)) - alpha_2 lap2(phi);
+    # c4 derivative of the products, single grid spacing
+    b = _B("ape_burgers3d", 3, ["u", "v", "w"], ["u_momentum", "v_momentum", "w_momentum"])
+    u, v, w = b.F()
+    a2, b1 = b.c("alpha_2", _k("alpha_2")), b.c("beta_1", _k("beta_1"))
+    g = lambda q, ax: _d1c4(b, q, ax, "dx")
+    lap = lambda q: _d2c2(b, q, 0, "dx") + _d2c2(b, q, 1, "dx") + _d2c2(b, q, 2, "dx")
+    res = []
+    for phi in (u, v, w):
+        conv = 0.5 * (g(phi * u, 0) + g(phi * v, 1) + g(phi * w, 2))
+        res.append(_ddt(b, phi) + b1 * conv - a2 * lap(phi))
+    return b.done(res, **T3D)
+
+
+def _swift_hohenberg3d():
+    # SwiftHohenberg3DPDELoss :3782-3876 — R = u_t - (r-k^2) u + 2k lap(u) + lap(lap(u)) - u^2 + u^3
+    b = _B("swift_hohenberg3d", 3, ["u"], ["swift_hohenberg"])
+    u = b.F()
+    lin, twok = b.c("linear_coeff", _k("linear_coeff")), b.c("two_k", lambda p: 2.0 * p["k"])
+    lap = lambda q: _d2c2(b, q, 0, "dx") + _d2c2(b, q, 1, "dx") + _d2c2(b, q, 2, "dx")
+    lu = lap(u)
+    R = _ddt(b, u) - lin * u + twok * lu + lap(lu) - u * u + u * u * u
+    return b.done([R], **T3D)
+
+
+def _heat3d():
+    # No class of this name exists in the reference snapshot; arithmetic follows verify_3d_heat,
+    # finetune/generate_analytical_3d.py:160-178 (7-point c2 Laplacian, periodic, central time), with the
+    # per-sample alpha and dict keys of the call site finetune/train_heat_3d_lora_v3.py:144-172
+    b = _B("heat3d", 3, ["u"], ["heat"])
+    u = b.F()
+    al = b.s("alpha")
+    lap = _d2c2(b, u, 0, "dx") + _d2c2(b, u, 1, "dy") + _d2c2(b, u, 2, "dz")
+    return b.done([_ddt(b, u) - al * lap], **T3D)
+
+
+for _f in (_burgers1d, _advection1d, _heat1d, _ape_burgers1d, _ks1d, _kdv1d, _tg2d, _advdiff2d, _anisodiff2d,
+           _wave2d, _ape_burgers2d, _nspwc, _kp2d, _shear_flow, _burgers2d_ch, _active_matter,
+           _rayleigh_benard, _turbulent_radiative, _wave_gauss, _burgers2d_ghost, _gray_scott_fd,
+           _gray_scott_pw, _advection3d, _ape_burgers3d, _swift_hohenberg3d, _heat3d):
+    _reg(_f())
+
+PDE_IDS = {name: i for i, name in enumerate(SPECS)}

@@ -1,0 +1,172 @@
+"""NumPy interpreter of the symbolic PDE specs (TEST INFRASTRUCTURE ONLY).
+
+It evaluates the same expression trees the code generator prints as HIP (residuals and the
+gather-form adjoint) on whole arrays, in fp64, so that the specs, the symbolic differentiation and
+the host-side weight logic of pde_amd/losses.py can be checked on a machine without a GPU.  It is
+installed through pde_amd.functional.set_backend by the CPU tests and is never used by the product.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from pde_amd.stencil import expr as X
+from pde_amd.stencil.specs import SPECS
+
+
+def _shift(a, o, periodic, axes0):
+    """result[i] = a[i + o] per spatial axis; zero fill on wall axes."""
+    out = a
+    for ax in range(3):
+        k = o[ax]
+        if k == 0:
+            continue
+        d = axes0 + ax
+        if periodic[ax]:
+            out = np.roll(out, -k, axis=d)
+        else:
+            res = np.zeros_like(out)
+            n = out.shape[d]
+            src = [slice(None)] * out.ndim
+            dst = [slice(None)] * out.ndim
+            if abs(k) < n:
+                if k > 0:
+                    src[d], dst[d] = slice(k, n), slice(0, n - k)
+                else:
+                    src[d], dst[d] = slice(0, n + k), slice(-k, n)
+                res[tuple(dst)] = out[tuple(src)]
+            out = res
+    return out
+
+
+class _Env:
+    def __init__(self, spec, fields, aux, sparams, consts, T, frames_of):
+        self.spec, self.fields, self.aux, self.sp, self.c = spec, fields, aux, sparams, consts
+        self.T = T
+        self.frames_of = frames_of      # ot -> (array-of-frames selector)
+        self.G = None
+        self.cache = {}
+
+    def ev(self, e):
+        k = e.key()
+        if k in self.cache:
+            return self.cache[k]
+        r = self._ev(e)
+        self.cache[k] = r
+        return r
+
+    def _ev(self, e):
+        s = self.spec
+        if isinstance(e, X.Num):
+            return e.v
+        if isinstance(e, X.Par):
+            if e.kind == "c":
+                return self.c[e.i]
+            return self.sp[e.i].reshape(-1, 1, 1, 1, 1)
+        if isinstance(e, X.Ref):
+            return _shift(self.frames_of(self.fields[e.f], e.ot), e.o, s.periodic, 2)
+        if isinstance(e, X.GRef):
+            return _shift(self.frames_of(self.G[e.k], e.ot), e.o, s.periodic, 2)
+        if isinstance(e, X.Aux):
+            return _shift(self.aux[e.a][:, None], e.o, s.periodic, 2)
+        if isinstance(e, X.Add):
+            out = 0.0
+            for t in e.terms:
+                out = out + self.ev(t)
+            return out
+        if isinstance(e, X.Mul):
+            out = 1.0
+            for t in e.factors:
+                out = out * self.ev(t)
+            return out
+        if isinstance(e, X.Recip):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return 1.0 / self.ev(e.e)
+        if isinstance(e, X.Sel):
+            return np.where(self.ev(e.c) >= 0, self.ev(e.a), self.ev(e.b))
+        if isinstance(e, X.PSel):
+            n = self.shape[2 + e.p.axis]
+            idx = np.arange(n)
+            m = (idx == (n - 1 - e.p.k)) if e.p.hi else (idx == e.p.k)
+            view = [1, 1, 1, 1, 1]
+            view[2 + e.p.axis] = n
+            return np.where(m.reshape(view), self.ev(e.a), self.ev(e.b))
+        raise TypeError(type(e))
+
+
+def _to5(t, ndim):
+    a = t.detach().cpu().double().numpy()
+    return a.reshape(a.shape[:2] + (1,) * (3 - ndim) + a.shape[2:])
+
+
+class InterpBackend:
+    name = "interp"
+
+    def _lattice_mask(self, prob, shape5):
+        m = np.ones(shape5[2:], dtype=bool)
+        for ax in range(3):
+            n = shape5[2 + ax]
+            idx = np.arange(n)
+            ok = (idx >= prob.lo[ax]) & (idx < n - prob.hi[ax])
+            view = [1, 1, 1]
+            view[ax] = n
+            m = m & ok.reshape(view)
+        return m
+
+    def _residuals(self, prob, fields, aux, sparams):
+        s = SPECS[prob.spec]
+        F = [_to5(f, s.ndim) for f in fields]
+        A = [x.detach().cpu().double().numpy().reshape((x.shape[0],) + (1,) * (3 - s.ndim) + tuple(x.shape[1:])) for x in aux]
+        SP = [p.detach().cpu().double().numpy() for p in sparams]
+        C = [float(np.float32(c)) for c in prob.consts]
+        B, T = F[0].shape[:2]
+        TR = T - s.tlo - s.thi
+        env = _Env(s, F, A, SP, C, T, lambda a, ot: a[:, s.tlo + ot: s.tlo + ot + TR])
+        env.shape = (B, TR) + F[0].shape[2:]
+        mask = self._lattice_mask(prob, F[0].shape)
+        with np.errstate(all="ignore"):
+            R = [np.where(mask, np.broadcast_to(env.ev(r), env.shape), 0.0) for r in s.residuals]
+        return s, F, A, SP, C, R, TR
+
+    def forward(self, prob, fields, aux, sparams, weights, store):
+        s, F, A, SP, C, R, TR = self._residuals(prob, fields, aux, sparams)
+        w = weights.detach().cpu().double().numpy()
+        B = F[0].shape[0]
+        sums = np.zeros((B, len(s.eqs)))
+        for k, r in enumerate(R):
+            sums[:, k] = (r ** 2 * w[k].reshape(1, TR, 1, 1, 1)).reshape(B, -1).sum(1) if TR > 0 else 0.0
+        dev = fields[0].device
+        resid = None
+        if store:
+            resid = [torch.tensor(r.reshape((B, TR) + tuple(fields[0].shape[2:])), dtype=torch.float32, device=dev) for r in R]
+        return torch.tensor(sums, dtype=torch.float64, device=dev), resid
+
+    def backward(self, prob, fields, aux, sparams, coef, resid):
+        s, F, A, SP, C, R, TR = self._residuals(prob, fields, aux, sparams)
+        cf = coef.detach().cpu().double().numpy()       # [B, NE, TR]
+        B, T = F[0].shape[:2]
+        sp_shape = F[0].shape[2:]
+        # G_k on every frame (zero outside the residual frames)
+        G = []
+        for k, r in enumerate(R):
+            g = np.zeros((B, T) + sp_shape)
+            if TR > 0:
+                g[:, s.tlo:s.tlo + TR] = r * cf[:, k].reshape(B, TR, 1, 1, 1)
+            G.append(g)
+
+        def frames(a, ot):   # frame tq + ot for every output frame tq, zero outside [0, T)
+            out = np.zeros((a.shape[0], T) + a.shape[2:])
+            lo, hi = max(0, -ot), min(T, T - ot)
+            if hi > lo:
+                out[:, lo:hi] = a[:, lo + ot:hi + ot]
+            return out
+
+        env = _Env(s, F, A, SP, C, T, frames)
+        env.G = G
+        env.shape = (B, T) + sp_shape
+        out = []
+        with np.errstate(all="ignore"):
+            for f, e in enumerate(s.adjoint):
+                g = np.broadcast_to(env.ev(e), env.shape) * 1.0
+                out.append(torch.tensor(g.reshape(fields[f].shape), dtype=torch.float32, device=fields[f].device))
+        return out

@@ -1,0 +1,132 @@
+"""HIP kernels (through the C ABI) against the reference's golden vectors and the CPU oracle.
+
+Tolerance: loss relative 1e-5, gradient relative L2 1e-5 (the bound the project states for fp32);
+the golden references are the reference classes run in fp64 on the same inputs.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import pde_amd.losses as PL
+from oracle import classes as OC
+from tests.helpers import GOLDEN, golden_cases, load_case, rel_l2
+
+TOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _run(mod, fields, extra):
+    fields = [f.clone().requires_grad_(True) for f in fields]
+    total, losses = mod(*fields, **extra)
+    total.backward()
+    return total, losses, [f.grad for f in fields]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden(name):
+    dev = _dev()
+    meta, kwargs, fields, extra, z = load_case(name, torch.float32, dev)
+    mod = getattr(PL, meta["cls"])(**kwargs).to(dev)
+    total, losses, grads = _run(mod, fields, extra)
+    ref_total = float(z["f64_total"])
+    assert abs(float(total) - ref_total) <= TOL * abs(ref_total)
+    ref_keys = sorted(k[9:] for k in z.files if k.startswith("f64_loss_"))
+    assert sorted(losses) == ref_keys
+    for k in ref_keys:
+        ref = float(z[f"f64_loss_{k}"])
+        assert abs(float(losses[k]) - ref) <= TOL * abs(ref) + 1e-30, k
+    for n, g in zip(meta["fields"], grads):
+        ref = z[f"f64_grad_{n}"]
+        got = g.cpu().numpy() if g is not None else np.zeros_like(ref)
+        assert rel_l2(got, ref) <= TOL, n
+
+
+def test_ghost_burgers_golden():
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, "pde_burgers2d_ghost.npz"))
+    m = json.loads(bytes(z["meta"]).decode())
+    pred = torch.tensor(z["in_pred"], dtype=torch.float32, device=dev, requires_grad=True)
+    total, lu, lv, ru, rv = PL.burgers_pde_loss(pred, m["nu"], dt=m["dt"], dx=m["dx"], dy=m["dy"])
+    total.backward()
+    assert abs(float(total) - float(z["f64_total"])) <= TOL * abs(float(z["f64_total"]))
+    assert rel_l2(ru.cpu().numpy(), z["f64_res_u"]) <= TOL
+    assert rel_l2(rv.cpu().numpy(), z["f64_res_v"]) <= TOL
+    assert rel_l2(pred.grad.cpu().numpy(), z["f64_grad_pred"]) <= TOL
+
+
+# moderate sizes with ragged tiles (extents that are not multiples of the tile) against the fp64 oracle
+SIZED = [
+    ("Burgers1DPDELoss", dict(dx=0.02, dt=0.01), (3, 7, 300), dict(nu=(0.005, 0.1))),
+    ("TaylorGreen2DPDELoss", dict(nx=72, ny=50, Lx=6.28, Ly=6.28, dt=0.01), (3, 6, 50, 72), dict(nu=(0.01, 0.1))),
+    ("ShearFlowPDELossNPINN", dict(nx=40, ny=70, Lx=1.0, Ly=2.0, dt=0.1), (2, 5, 40, 70), {}),
+    ("RayleighBenardFullPDELoss", dict(nx=48, ny=40, Lx=4.0, Ly=1.0, dt=0.25, skip_bl=3), (2, 5, 48, 40), dict(kappa=(1e-3, 1e-2))),
+    ("Burgers2DCHPDELoss", dict(nx=66, ny=20, dt=0.01), (2, 4, 20, 66), dict(nu=(0.01, 0.1))),
+    ("KP2DPDELoss", dict(dx=0.1, dy=0.1, dt=0.01, skip_boundary=5), (2, 5, 30, 70), {}),
+    ("NSPwCPDELoss", dict(nx=70, ny=33, dt=0.05), (2, 5, 33, 70), {}),
+    ("TurbulentRadiativePDELoss", dict(nx=20, ny=70, dt=1.5, skip_bl=2), (2, 4, 20, 70), {}),
+    ("APEBenchBurgers3DPDELoss", dict(nx=20, Lx=1.0, dt=1.0), (1, 4, 9, 10, 70), {}),
+    ("Advection3DPDELoss", dict(dx=0.1, dy=0.2, dz=0.3, dt=0.05), (2, 4, 5, 9, 66), dict(a=(-1, 1), b=(-1, 1), c=(-1, 1))),
+    ("SwiftHohenberg3DPDELoss", dict(domain_extent=6.0, num_points=12, dt=0.1), (1, 4, 6, 10, 65), {}),
+    ("Heat3DPDELoss", dict(nx=6, ny=10, nz=65, Lx=1.0, Ly=1.0, Lz=1.0, dt=0.01), (2, 4, 6, 10, 65), dict(alpha=(0.005, 0.05))),
+    ("GrayScottPDELoss", dict(nx=24, ny=70, dx=0.1, dy=0.1, dt=10.0), (2, 5, 24, 70), {}),
+]
+
+
+@pytest.mark.parametrize("cls,kw,shape,ps", SIZED, ids=[s[0] for s in SIZED])
+def test_ragged_sizes_vs_oracle(cls, kw, shape, ps):
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    spec = PL.SPECS[getattr(PL, cls).SPEC] if getattr(PL, cls).SPEC else PL.SPECS["gray_scott_pw"]
+    nf = len(spec.fields) if cls != "GrayScottPDELoss" else 2
+    fields = [torch.randn(shape, generator=g) * 0.5 for _ in range(nf)]
+    if cls == "TurbulentRadiativePDELoss":
+        fields[2] = fields[2].abs() + 0.5
+    extra = {k: lo + (hi - lo) * torch.rand(shape[0], generator=g) for k, (lo, hi) in ps.items()}
+    mod = getattr(PL, cls)(**kw).to(dev)
+    total, losses, grads = _run(mod, [f.to(dev) for f in fields], {k: v.to(dev) for k, v in extra.items()})
+    f64 = [f.double().requires_grad_(True) for f in fields]
+    ot, ol = OC.build(cls, **kw)(*f64, **{k: v.double() for k, v in extra.items()})
+    ot.backward()
+    assert abs(float(total) - float(ot)) <= TOL * abs(float(ot))
+    for k in ol:
+        assert abs(float(losses[k]) - float(ol[k])) <= TOL * abs(float(ol[k])) + 1e-30, k
+    for gr, f in zip(grads, f64):
+        assert rel_l2(gr.cpu().numpy(), f.grad.numpy()) <= TOL
+
+
+def test_no_grad_and_partial_requires_grad():
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    u, v, p = (torch.randn(2, 5, 20, 70, generator=g).to(dev) for _ in range(3))
+    mod = PL.TaylorGreen2DPDELoss(nx=70, ny=20).to(dev)
+    with torch.no_grad():
+        t0, _ = mod(u, v, p, nu=torch.tensor([0.02, 0.05], device=dev))
+    u.requires_grad_(True)
+    t1, _ = mod(u, v, p, nu=torch.tensor([0.02, 0.05], device=dev))
+    (3.0 * t1).backward()
+    assert torch.allclose(t0, t1.detach())
+    assert u.grad is not None and v.grad is None
+    # frames 0 and T-1 only receive the time-difference contribution
+    assert torch.isfinite(u.grad).all()
+
+
+def test_cpu_tensors_are_rejected():
+    mod = PL.Burgers1DPDELoss()
+    with pytest.raises(RuntimeError):
+        mod(torch.randn(2, 5, 64), torch.tensor([0.01, 0.02]))
+
+
+def test_two_frames_gives_empty_lattice():
+    dev = _dev()
+    mod = PL.Heat1DPDELoss().to(dev)
+    total, _ = mod(torch.randn(2, 2, 64, device=dev), torch.tensor([0.01, 0.02], device=dev))
+    assert torch.isnan(total)      # mean over an empty residual lattice, as in the reference

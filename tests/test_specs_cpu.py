@@ -1,0 +1,109 @@
+"""Specs, symbolic adjoints and the host-side loss classes, checked on the CPU.
+
+pde_amd's classes run here on the NumPy spec interpreter (tests/spec_interp.py) instead of the HIP
+kernels; results are compared with the golden vectors of the reference and with the CPU oracle.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pde_amd.losses as PL
+from oracle import classes as OC
+from pde_amd import functional as PF
+from tests.helpers import GOLDEN, golden_cases, load_case, rel_l2
+from tests.spec_interp import InterpBackend
+
+
+@pytest.fixture(autouse=True)
+def interp_backend():
+    old = PF.set_backend(InterpBackend())
+    yield
+    PF.set_backend(old)
+
+
+def _run(mod, fields, extra):
+    fields = [f.clone().requires_grad_(True) for f in fields]
+    total, losses = mod(*fields, **extra)
+    total.backward()
+    return total, losses, [f.grad for f in fields]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_classes_match_reference_golden(name):
+    meta, kwargs, fields, extra, z = load_case(name, torch.float32)
+    mod = getattr(PL, meta["cls"])(**kwargs)
+    total, losses, grads = _run(mod, fields, extra)
+    ref_total = float(z["f32_total"])
+    assert abs(float(total) - ref_total) <= 2e-5 * abs(ref_total)
+    ref_keys = sorted(k[9:] for k in z.files if k.startswith("f32_loss_"))
+    assert sorted(losses) == ref_keys
+    for k in ref_keys:
+        ref = float(z[f"f64_loss_{k}"])
+        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref) + 1e-30, k
+    for n, g in zip(meta["fields"], grads):
+        ref = z[f"f64_grad_{n}"]
+        got = g.numpy() if g is not None else np.zeros_like(ref)
+        assert rel_l2(got, ref) <= 2e-5, n
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_classes_match_oracle_tightly(name):
+    """Same fp32-rounded inputs through the fp64 oracle: differences are fp32 constant rounding only."""
+    meta, kwargs, fields, extra, z = load_case(name, torch.float32)
+    mod = getattr(PL, meta["cls"])(**kwargs)
+    total, losses, grads = _run(mod, fields, extra)
+    f64 = [f.double().requires_grad_(True) for f in fields]
+    e64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in extra.items()}
+    ototal, olosses = OC.build(meta["cls"], **kwargs)(*f64, **e64)
+    ototal.backward()
+    assert abs(float(total) - float(ototal)) <= 3e-6 * abs(float(ototal))
+    for n, g, f in zip(meta["fields"], grads, f64):
+        ref = f.grad.numpy() if f.grad is not None else np.zeros(f.shape)
+        got = g.numpy() if g is not None else np.zeros_like(ref)
+        assert rel_l2(got, ref) <= 3e-6, n
+
+
+def test_ghost_burgers_function():
+    z = np.load(os.path.join(GOLDEN, "pde_burgers2d_ghost.npz"))
+    m = json.loads(bytes(z["meta"]).decode())
+    pred = torch.tensor(z["in_pred"], dtype=torch.float32, requires_grad=True)
+    total, lu, lv, ru, rv = PL.burgers_pde_loss(pred, m["nu"], dt=m["dt"], dx=m["dx"], dy=m["dy"])
+    total.backward()
+    assert abs(float(total) - float(z["f64_total"])) <= 2e-5 * abs(float(z["f64_total"]))
+    assert abs(float(lu) - float(z["f64_loss_u"])) <= 2e-5 * abs(float(z["f64_loss_u"]))
+    assert ru.shape == z["f64_res_u"].shape
+    assert rel_l2(ru.numpy(), z["f64_res_u"]) <= 2e-5
+    assert rel_l2(rv.numpy(), z["f64_res_v"]) <= 2e-5
+    assert rel_l2(pred.grad.numpy(), z["f64_grad_pred"]) <= 2e-5
+
+
+def test_heat3d_matches_oracle():
+    g = torch.Generator().manual_seed(3)
+    u = torch.randn(2, 5, 6, 5, 7, generator=g)
+    alpha = torch.tensor([0.01, 0.03])
+    kw = dict(nx=6, ny=5, nz=7, Lx=1.0, Ly=1.5, Lz=2.0, dt=0.01, eq_scales={"heat": 3.0})
+    mod = PL.Heat3DPDELoss(**kw)
+    total, losses, grads = _run(mod, [u], dict(alpha=alpha))
+    u64 = u.double().requires_grad_(True)
+    ot, _ = OC.build("Heat3DPDELoss", **kw)(u64, alpha.double())
+    ot.backward()
+    assert sorted(losses) == ["heat", "total"]
+    assert abs(float(total) - float(ot)) <= 3e-6 * abs(float(ot))
+    assert rel_l2(grads[0].numpy(), u64.grad.numpy()) <= 3e-6
+
+
+def test_gray_scott_fd4_matches_oracle():
+    g = torch.Generator().manual_seed(4)
+    A, B = torch.rand(2, 5, 12, 10, generator=g), torch.rand(2, 5, 12, 10, generator=g)
+    kw = dict(nx=12, ny=10, dx=0.1, dy=0.15, dt=10.0)
+    mod = PL.GrayScottPDELoss(laplacian="fd4", **kw)
+    total, losses, grads = _run(mod, [A, B], {})
+    a64, b64 = A.double().requires_grad_(True), B.double().requires_grad_(True)
+    ot, _ = OC.build("GrayScottPDELoss", **kw)(a64, b64, laplacian="fd4")
+    ot.backward()
+    assert abs(float(total) - float(ot)) <= 3e-6 * abs(float(ot))
+    assert rel_l2(grads[0].numpy(), a64.grad.numpy()) <= 3e-6
+    assert rel_l2(grads[1].numpy(), b64.grad.numpy()) <= 3e-6
