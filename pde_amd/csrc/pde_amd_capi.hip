@@ -73,12 +73,13 @@ struct Ops {
                  void* ws, size_t ws_bytes_given, hipStream_t stream) {
     int st = check(p);
     if (st) return st;
-    if (!fields || !weights || !sums || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
+    if (!sums) return PDE_AMD_EINVAL;
     const long items = fwd_items(p);
     if (items <= 0) {   // no residual frame: the sums are empty sums
       (void)hipMemsetAsync(sums, 0, sizeof(double) * p->batch * P::NE, stream);
       return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
     }
+    if (!fields || !weights || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
     if (!ws || ws_bytes_given < ws_bytes(p)) return PDE_AMD_EWORKSPACE;
     Args a;
     fill_args(a, p, fields, aux, sparams);
@@ -105,13 +106,14 @@ struct Ops {
                  float* const* grads, void* ws, size_t ws_bytes_given, hipStream_t stream) {
     int st = check(p);
     if (st) return st;
-    if (!fields || !coef || !grads || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
+    if (!grads) return PDE_AMD_EINVAL;
     const long tr = p->frames - P::TLO - P::THI;
     if (tr <= 0) {      // the loss does not depend on the fields
       for (int f = 0; f < P::NF; ++f)
         (void)hipMemsetAsync(grads[f], 0, sizeof(float) * (size_t)p->batch * p->frames * p->n[0] * p->n[1] * p->n[2], stream);
       return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
     }
+    if (!fields || !coef || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
     if (!resid_in) return PDE_AMD_EINVAL;   // recompute mode is not built for this PDE
     Args a;
     fill_args(a, p, fields, aux, sparams);
