@@ -47,6 +47,7 @@ typedef struct pde_amd_pde_info {
   int32_t id, ndim, n_fields, n_eqs, n_aux, n_consts, n_sparams;
   int32_t t_lo, t_hi;       /* residual frames are t_lo <= t < frames - t_hi */
   int32_t halo[3];          /* largest spatial reach of the residual stencil per axis */
+  int32_t can_recompute;    /* 1 when pde_amd_residual_backward accepts resid_in == NULL */
   const char* name;
 } pde_amd_pde_info;
 
@@ -63,22 +64,29 @@ size_t pde_amd_residual_workspace_bytes(const pde_amd_problem* prob);
  *   sums[b][k] = sum over residual frames t and lattice sites of  weights[k][t] * R_k(b, t, site)^2
  * in fp64.  weights is [n_eqs][T_res]; with weights[k][t] = w_k / (s_k^2 N) the column sums of `sums`
  * are the reference's per-equation losses (per-timestep scales: w_k / (s_t[t]^2 N)).
+ * totals (nullable): fp32 [n_eqs + 1] = the column sums of `sums` and, last, their left-to-right fp32
+ * sum, i.e. the reference's `losses[k]` and `total = sum(losses.values())` (:1922).
  * resid_out (host array of n_eqs device pointers, or NULL): when given, R_k is also written on the full
  * grid as [B, T_res, n0, n1, n2] with zeros outside the lattice. */
 int pde_amd_residual_forward(const pde_amd_problem* prob,
                              const float* const* fields, const float* const* aux,
                              const float* const* sparams, const float* weights,
-                             double* sums, float* const* resid_out,
+                             double* sums, float* totals, float* const* resid_out,
                              void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of the same functions (autograd replay in the reference):
- *   grads[f] = d( sum_{b,k,t,site} 0.5 * coef[b][k][t] * R_k^2 ) / d fields[f]     on every frame,
- * i.e. with coef = 2 * weights * upstream-gradient it is the gradient of the reference loss.
- * coef is [B][n_eqs][T_res].  resid_in: the residuals a forward call stored (stored mode), or NULL to
- * recompute them inside the kernel. Every element of every grads[f] is written exactly once. */
+/* Backward of the same functions (autograd replay in the reference).  With
+ *   u[b][k] = upstream[k] + upstream[n_eqs] + upstream_sums[b][k]
+ * (upstream: host array of n_eqs + 1 device scalars, the gradients w.r.t. totals[k] and totals[n_eqs], NULL
+ * entries count as 0; upstream_sums: device [B][n_eqs] fp64 gradient w.r.t. `sums`, nullable) it writes
+ *   grads[f] = d( sum_{b,k,t,site} u[b][k] * weights[k][t] * R_k^2 ) / d fields[f]      on every frame.
+ * The upstream values are read on the device, so no host synchronisation is needed to chain it behind
+ * a loss such as lambda_pde * total (finetune/train_taylor_green_2d_lora_v3.py:506-512).
+ * resid_in: the residuals a forward call stored (stored mode), or NULL to recompute them inside the
+ * kernel (only when pde_amd_pde_info.can_recompute).  Every element of every grads[f] is written once. */
 int pde_amd_residual_backward(const pde_amd_problem* prob,
                               const float* const* fields, const float* const* aux,
-                              const float* const* sparams, const float* coef,
+                              const float* const* sparams, const float* weights,
+                              const float* const* upstream, const double* upstream_sums,
                               const float* const* resid_in, float* const* grads,
                               void* workspace, size_t workspace_bytes, void* stream);
 

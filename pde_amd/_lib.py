@@ -27,7 +27,8 @@ class Problem(C.Structure):
 class PdeInfo(C.Structure):
     _fields_ = [("id", C.c_int32), ("ndim", C.c_int32), ("n_fields", C.c_int32), ("n_eqs", C.c_int32),
                 ("n_aux", C.c_int32), ("n_consts", C.c_int32), ("n_sparams", C.c_int32),
-                ("t_lo", C.c_int32), ("t_hi", C.c_int32), ("halo", C.c_int32 * 3), ("name", C.c_char_p)]
+                ("t_lo", C.c_int32), ("t_hi", C.c_int32), ("halo", C.c_int32 * 3), ("can_recompute", C.c_int32),
+                ("name", C.c_char_p)]
 
 
 _lib = None
@@ -40,11 +41,12 @@ SIGNATURES = {
     "pde_amd_status_string": (C.c_char_p, [C.c_int]),
     "pde_amd_residual_workspace_bytes": (C.c_size_t, [C.POINTER(Problem)]),
     "pde_amd_residual_forward": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
-                                           C.c_void_p, C.c_size_t, C.c_void_p]),
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]),
     "pde_amd_residual_backward": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                            C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p),
-                                            C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]),
+                                            C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
 }
 
 
@@ -71,7 +73,20 @@ def check(status: int, what: str):
 
 
 def ptr_array(tensors, n):
+    """Host array of device pointers; None entries become NULL."""
     arr = (C.c_void_p * max(n, 1))()
     for i, t in enumerate(tensors):
-        arr[i] = t.data_ptr()
+        arr[i] = t.data_ptr() if t is not None else None
     return arr
+
+
+_info_cache = {}
+
+
+def pde_info(name: str) -> PdeInfo:
+    if name not in _info_cache:
+        l = lib()
+        i = PdeInfo()
+        check(l.pde_amd_get_pde_info(l.pde_amd_pde_id(name.encode()), C.byref(i)), f"pde_info({name})")
+        _info_cache[name] = i
+    return _info_cache[name]

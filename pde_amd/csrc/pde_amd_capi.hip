@@ -1,4 +1,4 @@
-// C ABI (include/pde_amd.h) over the stencil kernels: validation, geometry, launches.
+// C ABI (include/pde_amd.h) over the stencil kernels: validation, geometry, kernel choice, launches.
 #include "../../include/pde_amd.h"
 #include "stencil_kernels.hpp"
 #include <string.h>
@@ -13,24 +13,34 @@ struct PdeVTable {
   pde_amd_pde_info info;
   size_t (*ws_bytes)(const pde_amd_problem*);
   int (*fwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
-             double*, float* const*, void*, size_t, hipStream_t);
+             double*, float*, float* const*, void*, size_t, hipStream_t);
   int (*bwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
-             const float* const*, float* const*, void*, size_t, hipStream_t);
+             const float* const*, const double*, const float* const*, float* const*, void*, size_t, hipStream_t);
 };
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
+// Frames per marching workgroup: whole clips when samples x tiles already fill the chip, shorter chunks
+// (each re-reads a few frames at its ends) when they do not.
+static inline int pick_chunk(long blocks_per_chunking, int frames) {
+  const long want = 768;   // about three workgroups per CU
+  int nchunk = (int)((want + blocks_per_chunking - 1) / blocks_per_chunking);
+  if (nchunk < 1) nchunk = 1;
+  int chunk = cdiv(frames, nchunk);
+  if (chunk < 4) chunk = frames < 4 ? frames : 4;
+  return chunk;
+}
+
 template <class P>
 struct Ops {
-  static bool fill_geom(const pde_amd_problem* p, Geom& g, int t0, int t1, int t2) {
+  static void fill_geom(const pde_amd_problem* p, Geom& g, int t0, int t1, int t2) {
     g.B = p->batch; g.T = p->frames; g.TR = p->frames - P::TLO - P::THI;
     g.N0 = p->n[0]; g.N1 = p->n[1]; g.N2 = p->n[2];
     g.lo0 = p->lo[0]; g.lo1 = p->lo[1]; g.lo2 = p->lo[2];
     g.hi0 = p->hi[0]; g.hi1 = p->hi[1]; g.hi2 = p->hi[2];
     g.nt0 = cdiv(g.N0, t0); g.nt1 = cdiv(g.N1, t1); g.nt2 = cdiv(g.N2, t2);
     g.S = (long)g.N0 * g.N1 * g.N2;
-    return true;
   }
 
   static int check(const pde_amd_problem* p) {
@@ -40,7 +50,8 @@ struct Ops {
     if (P::ND < 2 && p->n[1] != 1) return PDE_AMD_ESHAPE;
     if ((long)p->n[0] * p->n[1] * p->n[2] >= (1L << 31)) return PDE_AMD_ESHAPE;
     // a periodic axis must be at least as long as the widest halo any tile loads along it
-    const int h0 = max3(P::RH0, P::GH0, P::AH0), h1 = max3(P::RH1, P::GH1, P::AH1), h2 = max3(P::RH2, P::GH2, P::AH2);
+    const int h0 = max3(P::RH0 + P::GH0, P::RT0, P::AH0), h1 = max3(P::RH1 + P::GH1, P::RT1, P::AH1),
+              h2 = max3(P::RH2 + P::GH2, P::RT2, P::AH2);
     if (P::PER0 && p->n[0] < h0) return PDE_AMD_ESHAPE;
     if (P::PER1 && p->n[1] < h1) return PDE_AMD_ESHAPE;
     if (P::PER2 && p->n[2] < h2) return PDE_AMD_ESHAPE;
@@ -49,14 +60,14 @@ struct Ops {
     return PDE_AMD_OK;
   }
 
-  static long fwd_items(const pde_amd_problem* p) {
-    const long tr = p->frames - P::TLO - P::THI;
-    if (tr <= 0) return 0;
-    return tr * cdiv(p->n[0], P::FT0) * cdiv(p->n[1], P::FT1) * cdiv(p->n[2], P::FT2);
+  static long fwd_tiles(const pde_amd_problem* p) {
+    return (long)cdiv(p->n[0], P::FT0) * cdiv(p->n[1], P::FT1) * cdiv(p->n[2], P::FT2);
   }
 
   static size_t ws_bytes(const pde_amd_problem* p) {
-    return (size_t)(p->batch * fwd_items(p)) * P::NE * sizeof(double) + 256;
+    const long tr = p->frames - P::TLO - P::THI;
+    if (tr <= 0) return 256;
+    return (size_t)(p->batch * tr * fwd_tiles(p)) * P::NE * sizeof(double) + 256;
   }
 
   static void fill_args(Args& a, const pde_amd_problem* p, const float* const* fields, const float* const* aux,
@@ -69,14 +80,15 @@ struct Ops {
   }
 
   static int fwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
-                 const float* const* sparams, const float* weights, double* sums, float* const* resid_out,
-                 void* ws, size_t ws_bytes_given, hipStream_t stream) {
+                 const float* const* sparams, const float* weights, double* sums, float* totals,
+                 float* const* resid_out, void* ws, size_t ws_bytes_given, hipStream_t stream) {
     int st = check(p);
     if (st) return st;
     if (!sums) return PDE_AMD_EINVAL;
-    const long items = fwd_items(p);
-    if (items <= 0) {   // no residual frame: the sums are empty sums
+    const long tr = p->frames - P::TLO - P::THI;
+    if (tr <= 0) {   // no residual frame: the sums are empty sums
       (void)hipMemsetAsync(sums, 0, sizeof(double) * p->batch * P::NE, stream);
+      if (totals) (void)hipMemsetAsync(totals, 0, sizeof(float) * (P::NE + 1), stream);
       return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
     }
     if (!fields || !weights || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
@@ -86,51 +98,75 @@ struct Ops {
     fill_geom(p, a.geo, P::FT0, P::FT1, P::FT2);
     a.wt = weights;
     a.partial = reinterpret_cast<double*>(ws);
-    const long nwg = (long)p->batch * items;
-    if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+    const long tiles = fwd_tiles(p);
+    long items;   // partial sums per sample
     if (resid_out) {
       for (int k = 0; k < P::NE; ++k) {
         if (!resid_out[k]) return PDE_AMD_EINVAL;
         a.rout[k] = resid_out[k];
       }
-      hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+      items = tr * tiles;
+      if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+      hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
+    } else if constexpr (FwdMarchFits<P>::value) {
+      a.chunk = pick_chunk(p->batch * tiles, (int)tr);
+      items = cdiv((int)tr, a.chunk) * tiles;
+      if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+      hipLaunchKernelGGL((fwd_march_kernel<P>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
     } else {
-      hipLaunchKernelGGL((fwd_kernel<P, false>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+      items = tr * tiles;
+      if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+      hipLaunchKernelGGL((fwd_kernel<P, false>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
     }
     hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(p->batch), dim3(256), 0, stream, a.partial, sums, (int)items);
+    if (totals) hipLaunchKernelGGL((totals_kernel<P::NE>), dim3(1), dim3(64), 0, stream, sums, totals, p->batch);
     return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
   }
 
   static int bwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
-                 const float* const* sparams, const float* coef, const float* const* resid_in,
-                 float* const* grads, void* ws, size_t ws_bytes_given, hipStream_t stream) {
+                 const float* const* sparams, const float* weights, const float* const* upstream,
+                 const double* upstream_sums, const float* const* resid_in, float* const* grads,
+                 void* ws, size_t ws_bytes_given, hipStream_t stream) {
+    (void)ws; (void)ws_bytes_given;
     int st = check(p);
     if (st) return st;
     if (!grads) return PDE_AMD_EINVAL;
+    for (int f = 0; f < P::NF; ++f)
+      if (!grads[f]) return PDE_AMD_EINVAL;
     const long tr = p->frames - P::TLO - P::THI;
     if (tr <= 0) {      // the loss does not depend on the fields
       for (int f = 0; f < P::NF; ++f)
         (void)hipMemsetAsync(grads[f], 0, sizeof(float) * (size_t)p->batch * p->frames * p->n[0] * p->n[1] * p->n[2], stream);
       return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
     }
-    if (!fields || !coef || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
-    if (!resid_in) return PDE_AMD_EINVAL;   // recompute mode is not built for this PDE
+    if (!fields || !weights || (!upstream && !upstream_sums) || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
     Args a;
     fill_args(a, p, fields, aux, sparams);
     fill_geom(p, a.geo, P::BT0, P::BT1, P::BT2);
-    a.wt = coef;
-    for (int k = 0; k < P::NE; ++k) {
-      if (!resid_in[k]) return PDE_AMD_EINVAL;
-      a.r[k] = resid_in[k];
+    a.wt = weights;
+    a.gsums = upstream_sums;
+    if (upstream)
+      for (int k = 0; k <= P::NE; ++k) a.ups[k] = upstream[k];
+    for (int f = 0; f < P::NF; ++f) a.g[f] = grads[f];
+    const long tiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+    if (resid_in) {
+      for (int k = 0; k < P::NE; ++k) {
+        if (!resid_in[k]) return PDE_AMD_EINVAL;
+        a.r[k] = resid_in[k];
+      }
+      const long nwg = (long)p->batch * p->frames * tiles;
+      if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+      hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+    } else {
+      if constexpr (BwdMarchFits<P>::value) {
+        a.chunk = pick_chunk(p->batch * tiles, p->frames);
+        const long nwg = (long)p->batch * cdiv(p->frames, a.chunk) * tiles;
+        if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+        hipLaunchKernelGGL((bwd_march_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+      } else {
+        return PDE_AMD_EINVAL;   // this PDE has no recomputing adjoint: pass the stored residuals
+      }
     }
-    for (int f = 0; f < P::NF; ++f) {
-      if (!grads[f]) return PDE_AMD_EINVAL;
-      a.g[f] = grads[f];
-    }
-    const long nwg = (long)p->batch * p->frames * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
-    if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
-    hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
-    (void)ws; (void)ws_bytes_given;
     return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
   }
 
@@ -141,6 +177,7 @@ struct Ops {
     v.info.halo[0] = P::RH0 > P::RT0 ? P::RH0 : P::RT0;
     v.info.halo[1] = P::RH1 > P::RT1 ? P::RH1 : P::RT1;
     v.info.halo[2] = P::RH2 > P::RT2 ? P::RH2 : P::RT2;
+    v.info.can_recompute = BwdMarchFits<P>::value ? 1 : 0;
     v.info.name = P::NAME;
     v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd;
     return v;
@@ -194,21 +231,22 @@ size_t pde_amd_residual_workspace_bytes(const pde_amd_problem* prob) {
 }
 
 int pde_amd_residual_forward(const pde_amd_problem* prob, const float* const* fields, const float* const* aux,
-                             const float* const* sparams, const float* weights, double* sums,
+                             const float* const* sparams, const float* weights, double* sums, float* totals,
                              float* const* resid_out, void* workspace, size_t workspace_bytes, void* stream) {
   const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
   if (!v) return PDE_AMD_EINVAL;
-  return v->fwd(prob, fields, aux, sparams, weights, sums, resid_out, workspace, workspace_bytes,
+  return v->fwd(prob, fields, aux, sparams, weights, sums, totals, resid_out, workspace, workspace_bytes,
                 static_cast<hipStream_t>(stream));
 }
 
 int pde_amd_residual_backward(const pde_amd_problem* prob, const float* const* fields, const float* const* aux,
-                              const float* const* sparams, const float* coef, const float* const* resid_in,
-                              float* const* grads, void* workspace, size_t workspace_bytes, void* stream) {
+                              const float* const* sparams, const float* weights, const float* const* upstream,
+                              const double* upstream_sums, const float* const* resid_in, float* const* grads,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
   if (!v) return PDE_AMD_EINVAL;
-  return v->bwd(prob, fields, aux, sparams, coef, resid_in, grads, workspace, workspace_bytes,
-                static_cast<hipStream_t>(stream));
+  return v->bwd(prob, fields, aux, sparams, weights, upstream, upstream_sums, resid_in, grads, workspace,
+                workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -35,8 +35,11 @@ struct Args {
   const float* r[MAXE];    // stored residuals [B, TR, S] per equation (backward, stored mode)
   float* rout[MAXE];       // residual output (forward, optional)
   float* g[MAXF];          // gradients
-  const float* wt;         // forward: weights [NE][TR]; backward: coefficients [B][NE][TR]
+  const float* wt;         // weights [NE][TR]
+  const float* ups[MAXE + 1];   // backward: upstream gradients of the per-equation losses and of their total (device scalars, nullable)
+  const double* gsums;     // backward: upstream gradient of sums[B][NE] (nullable)
   double* partial;         // forward: per-workgroup partial sums [nwg][NE]
+  int chunk;               // marching kernels: frames per workgroup
   float c[MAXC];
   Geom geo;
 };
@@ -214,6 +217,18 @@ __device__ __forceinline__ bool in_lattice(const Geom& g, int i0, int i1, int i2
   return i0 >= g.lo0 && i0 < g.N0 - g.hi0 && i1 >= g.lo1 && i1 < g.N1 - g.hi1 && i2 >= g.lo2 && i2 < g.N2 - g.hi2;
 }
 
+// G_k = coef * R_k with coef = 2 * weight[k][frame] * (dL/dloss_k + dL/dtotal) + 2 * weight * dL/dsums[b][k]
+template <class P>
+__device__ __forceinline__ void upstream_of(const Args& a, int b, float (&up)[P::NE]) {
+  const float gt = a.ups[P::NE] ? *a.ups[P::NE] : 0.0f;
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) {
+    float u = gt + (a.ups[k] ? *a.ups[k] : 0.0f);
+    if (a.gsums) u += (float)a.gsums[(long)b * P::NE + k];
+    up[k] = 2.0f * u;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: one workgroup = (sample, residual frame, tile)
 //   sums of wt[k][frame] * R_k^2 over the tile -> partial[work][k];   optional store of R_k
@@ -324,6 +339,27 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict_
   block_sum_store<NE, 256>(acc, red, sums + (long)b * NE);
 }
 
+// sums[B][NE] -> totals[k] = fp32(sum_b sums[b][k]) and totals[NE] = their fp32 sum (left to right)
+template <int NE>
+__global__ __launch_bounds__(64) void totals_kernel(const double* __restrict__ sums, float* __restrict__ totals, int B) {
+  double acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+  for (int b = threadIdx.x; b < B; b += 64) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) acc[k] += sums[(long)b * NE + k];
+  }
+  float tot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const double s = wave_sum(acc[k]);
+    const float f = (float)s;
+    tot += f;
+    if (threadIdx.x == 0) totals[k] = f;
+  }
+  if (threadIdx.x == 0) totals[NE] = tot;
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward, stored-residual mode: one workgroup = (sample, output frame tq, tile)
 //   G_k = coef[b][k][frame] * R_k is staged in LDS (with the adjoint's halo) and gathered
@@ -371,12 +407,14 @@ __global__ __launch_bounds__(P::NT) void bwd_stored_kernel(const Args a) {
   acc.tq = tq; acc.T = g.T; acc.tr0 = tq - P::TLO;
 
   // coefficients of the residual frames this output frame touches
+  float up[P::NE];
+  upstream_of<P>(a, b, up);
 #pragma unroll
   for (int s = 0; s < P::GTLO + P::GTHI + 1; ++s) {
     const int trs = tq + (s - P::GTLO) - P::TLO;
     const bool ok = trs >= 0 && trs < g.TR;
 #pragma unroll
-    for (int k = 0; k < P::NE; ++k) acc.cf[s][k] = ok ? a.wt[((long)b * P::NE + k) * g.TR + trs] : 0.0f;
+    for (int k = 0; k < P::NE; ++k) acc.cf[s][k] = ok ? up[k] * a.wt[k * g.TR + trs] : 0.0f;
   }
 
 #pragma unroll
@@ -444,6 +482,405 @@ __global__ __launch_bounds__(P::NT) void bwd_stored_kernel(const Args a) {
       P::adjoint(acc, gr);
 #pragma unroll
       for (int f = 0; f < P::NF; ++f) a.g[f][frame + acc.goff] = gr[f];
+    }
+  }
+}
+
+
+// ================================================================================================
+// Time-marching kernels: one workgroup owns a spatial tile of one sample and walks through the
+// frames, so every frame of every field is fetched from HBM once (plus halo) instead of once per
+// frame that references it.  Frames live in an LDS ring; the next frame is fetched into registers
+// while the current one is being used.
+// ================================================================================================
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// Per-thread share of one halo tile: element e = tid + j * NT of the tile, its in-frame global offset
+// (or -1 for a wall-side zero) computed once per workgroup; the same offsets serve every field and frame.
+template <class TL, bool P0, bool P1, bool P2, int NT>
+struct Stager {
+  static constexpr int EPT = (TL::SIZE + NT - 1) / NT;
+  int off[EPT];
+  __device__ __forceinline__ void init(int o0, int o1, int o2, const Geom& g) {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = threadIdx.x + j * NT;
+      const int l2 = i % TL::D2, rr = i / TL::D2, l1 = rr % TL::D1, l0 = rr / TL::D1;
+      bool ok = i < TL::SIZE;
+      const int c0 = wrap_coord<P0>(o0 + l0 - TL::H0, g.N0, ok);
+      const int c1 = wrap_coord<P1>(o1 + l1 - TL::H1, g.N1, ok);
+      const int c2 = wrap_coord<P2>(o2 + l2 - TL::H2, g.N2, ok);
+      off[j] = ok ? (c0 * g.N1 + c1) * g.N2 + c2 : -1;
+    }
+  }
+  __device__ __forceinline__ void fetch(float (&v)[EPT], const float* __restrict__ frame) const {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] = off[j] >= 0 ? frame[off[j]] : 0.0f;
+  }
+  __device__ __forceinline__ void store(const float (&v)[EPT], float* __restrict__ tile) const {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = threadIdx.x + j * NT;
+      if (EPT * NT == TL::SIZE || i < TL::SIZE) tile[i] = v[j];
+    }
+  }
+};
+
+// Residual accessor over the LDS ring: frame (tau + ot) sits in slot (tau + ot) mod NS.
+template <class P, class TL, class TX, int NS>
+struct RingAcc : SiteBase<P> {
+  const float* fr[NS];       // &slot_of(tau - TLO + i)[field 0][site]
+  const float* ldsx;
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    return fr[ot + P::TLO][f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + o2];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    return ldsx[x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + o2];
+  }
+  __device__ __forceinline__ float G(int, int, int, int, int) const { return 0.0f; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward, marching: workgroup = (sample, chunk of residual frames, tile)
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::NT) void fwd_march_kernel(const Args a) {
+  using TL = Tile<P::FT0, P::FT1, P::FT2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), cmax(P::RH2, P::RT2)>;
+  using TX = Tile<P::FT0, P::FT1, P::FT2, P::XH0, P::XH1, P::XH2>;
+  constexpr int NS = P::TLO + P::THI + 1;
+  constexpr bool AUX_ON = P::NA > 0;
+  constexpr int NT = P::NT;
+  constexpr int PPT = (TL::T0 * TL::T1 * TL::T2) / NT;
+  using ST = Stager<TL, P::PER0, P::PER1, P::PER2, NT>;
+  static_assert(PPT * NT == TL::T0 * TL::T1 * TL::T2, "tile must be a multiple of the workgroup");
+  static_assert(NT % TL::T2 == 0, "a wave must lie along the fastest axis");
+
+  __shared__ float s_f[NS * P::NF * TL::SIZE];
+  __shared__ float s_x[AUX_ON ? P::NA * TX::SIZE : 1];
+  __shared__ double s_red[(NT / 64) * P::NE];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int nchunk = (g.TR + a.chunk - 1) / a.chunk;
+  const int tile = w % ntile, rest = w / ntile;
+  const int ch = rest % nchunk, b = rest / nchunk;
+  const int ra = P::TLO + ch * a.chunk;                    // first residual frame of this chunk
+  const int rb = min(ra + a.chunk, g.T - P::THI);          // one past the last
+  const int o2 = (tile % g.nt2) * TL::T2, o1 = ((tile / g.nt2) % g.nt1) * TL::T1, o0 = (tile / (g.nt2 * g.nt1)) * TL::T0;
+
+  ST st;
+  st.init(o0, o1, o2, g);
+  const float* fb[P::NF];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
+
+  // prologue: frames ra-TLO .. ra+THI straight into their slots
+  for (int fr = ra - P::TLO; fr <= ra + P::THI; ++fr) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) {
+      float v[ST::EPT];
+      st.fetch(v, fb[f] + (long)fr * g.S);
+      st.store(v, s_f + ((fr % NS) * P::NF + f) * TL::SIZE);
+    }
+  }
+  if (AUX_ON) {
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x)
+      load_tile<TX, P::PER0, P::PER1, P::PER2, NT>(s_x + x * TX::SIZE, a.aux[x] + (long)b * g.S, o0, o1, o2, g, 1.0f);
+  }
+  __syncthreads();
+
+  RingAcc<P, TL, TX, NS> acc;
+  acc.cc = a.c;
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = a.sp[i][b];
+  acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
+
+  // the points this thread owns
+  int site[PPT], tsite[PPT], pi0[PPT], pi1[PPT], pi2[PPT];
+  bool active[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    int l0, l1, l2;
+    point_coords<P, TL>(p, l0, l1, l2);
+    pi0[p] = o0 + l0; pi1[p] = o1 + l1; pi2[p] = o2 + l2;
+    site[p] = TL::at(l0, l1, l2);
+    tsite[p] = TX::at(l0, l1, l2);
+    active[p] = pi0[p] < g.N0 && pi1[p] < g.N1 && pi2[p] < g.N2 && in_lattice<P>(g, pi0[p], pi1[p], pi2[p]);
+  }
+
+  double sum[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) sum[k] = 0.0;
+
+  for (int tau = ra; tau < rb; ++tau) {
+    // fetch the frame the NEXT step adds while this step computes; it replaces the oldest frame afterwards
+    const bool more = tau + 1 < rb;
+    const int fnew = tau + P::THI + 1;
+    float stage[P::NF][ST::EPT];
+    if (more) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
+    }
+
+    float wk[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) wk[k] = a.wt[k * g.TR + (tau - P::TLO)];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      if (active[p]) {
+        acc.i0 = pi0[p]; acc.i1 = pi1[p]; acc.i2 = pi2[p];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) acc.fr[i] = s_f + (((tau - P::TLO + i) % NS) * P::NF) * TL::SIZE + site[p];
+        acc.ldsx = s_x + tsite[p];
+        float R[P::NE];
+        P::residual(acc, R);
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) sum[k] += (double)(R[k] * R[k]) * (double)wk[k];
+      }
+    }
+    if (more) {
+      __syncthreads();   // every wave is done with the oldest frame
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % NS) * P::NF + f) * TL::SIZE);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  block_sum_store<P::NE, NT>(sum, s_red, a.partial + (long)w * P::NE);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward, marching with recomputation: workgroup = (sample, chunk of output frames, tile)
+//
+// For central-in-time residuals whose other-frame references are pointwise.  At step n the ring
+// holds F(n-1), F(n), F(n+1) with a halo wide enough to evaluate the residual on the tile plus the
+// adjoint's reach; G(n) = coef * R(n) is recomputed there into LDS, the spatial part of the adjoint of
+// frame n is gathered from it, and the gradient of frame n-1 is completed with the time part, which
+// needs G(n-2) and G(n) at the point itself (kept in registers).  Nothing but the fields is read and
+// every gradient element is written once.
+// ------------------------------------------------------------------------------------------------
+template <class P, class TF, class TG, class TX>
+struct MarchAdjAcc : SiteBase<P> {
+  const float* ldsg;         // &G tile[site] of the frame being gathered
+  const float* ldsf;         // &F tile[site] of the same frame
+  const float* ldsx;
+  float gm[MAXE], gp[MAXE];  // G at this point on the previous / next residual frame
+  __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
+    if (ot == 0) return ldsg[k * TG::SIZE + o0 * TG::S0 + o1 * TG::S1 + o2];
+    return ot < 0 ? gm[k] : gp[k];
+  }
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    return ldsf[f * TF::SIZE + o0 * TF::S0 + o1 * TF::S1 + o2];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    return ldsx[x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + o2];
+  }
+};
+
+template <class P>
+struct MarchOK {
+  static constexpr bool value = P::TLO == 1 && P::THI == 1 && (P::RT0 | P::RT1 | P::RT2) == 0 &&
+                                (P::GT0 | P::GT1 | P::GT2) == 0 && P::ATLO == 0 && P::ATHI == 0 &&
+                                P::GTLO <= 1 && P::GTHI <= 1;
+};
+
+constexpr int LDS_BUDGET = 96 * 1024;   // keep at least one other workgroup's worth of LDS free per CU
+
+template <class P>
+struct BwdMarchFits {
+  static constexpr int HB0 = cmax(P::GH0 + P::RH0, P::AH0), HB1 = cmax(P::GH1 + P::RH1, P::AH1), HB2 = cmax(P::GH2 + P::RH2, P::AH2);
+  using TF = Tile<P::BT0, P::BT1, P::BT2, HB0, HB1, HB2>;
+  using TG = Tile<P::BT0, P::BT1, P::BT2, P::GH0, P::GH1, P::GH2>;
+  static constexpr long BYTES = 4L * (3 * P::NF * TF::SIZE + P::NE * TG::SIZE);
+  static constexpr bool value = MarchOK<P>::value && BYTES <= LDS_BUDGET;
+};
+
+template <class P>
+struct FwdMarchFits {
+  using TL = Tile<P::FT0, P::FT1, P::FT2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), cmax(P::RH2, P::RT2)>;
+  static constexpr long BYTES = 4L * (P::TLO + P::THI + 1) * P::NF * TL::SIZE;
+  static constexpr bool value = BYTES <= 64 * 1024;
+};
+
+template <class P>
+__global__ __launch_bounds__(P::NT) void bwd_march_kernel(const Args a) {
+  constexpr int HB0 = cmax(P::GH0 + P::RH0, P::AH0), HB1 = cmax(P::GH1 + P::RH1, P::AH1), HB2 = cmax(P::GH2 + P::RH2, P::AH2);
+  using TF = Tile<P::BT0, P::BT1, P::BT2, HB0, HB1, HB2>;
+  using TG = Tile<P::BT0, P::BT1, P::BT2, P::GH0, P::GH1, P::GH2>;
+  using TX = Tile<P::BT0, P::BT1, P::BT2, cmax(P::XH0, P::GH0), cmax(P::XH1, P::GH1), cmax(P::XH2, P::GH2)>;
+  constexpr bool AUX_ON = P::NA > 0;
+  constexpr int NT = P::NT;
+  constexpr int PPT = (TG::T0 * TG::T1 * TG::T2) / NT;
+  constexpr int RPT = (TG::SIZE + NT - 1) / NT;      // region sites (tile + adjoint reach) per thread
+  using ST = Stager<TF, P::PER0, P::PER1, P::PER2, NT>;
+  static_assert(MarchOK<P>::value, "PDE not eligible for the marching adjoint");
+  static_assert(PPT * NT == TG::T0 * TG::T1 * TG::T2, "tile must be a multiple of the workgroup");
+  static_assert(NT % TG::T2 == 0, "a wave must lie along the fastest axis");
+
+  __shared__ float s_f[3 * P::NF * TF::SIZE];
+  __shared__ float s_g[P::NE * TG::SIZE];
+  __shared__ float s_x[AUX_ON ? P::NA * TX::SIZE : 1];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int nchunk = (g.T + a.chunk - 1) / a.chunk;
+  const int tile = w % ntile, rest = w / ntile;
+  const int ch = rest % nchunk, b = rest / nchunk;
+  const int qa = ch * a.chunk, qb = min(qa + a.chunk, g.T);     // output frames [qa, qb)
+  const int o2 = (tile % g.nt2) * TG::T2, o1 = ((tile / g.nt2) % g.nt1) * TG::T1, o0 = (tile / (g.nt2 * g.nt1)) * TG::T0;
+
+  ST st;
+  st.init(o0, o1, o2, g);
+  const float* fb[P::NF];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
+  float up[P::NE];
+  upstream_of<P>(a, b, up);
+
+  // residual frames whose G this chunk needs: n in [qa-1, qb] clipped to the lattice [1, T-1)
+  const int na = max(qa - 1, 1), nb = min(qb, g.T - 2);       // inclusive range of frames with non-zero G
+  // frames to have in the ring before the first step (n = qa-1): n-1, n, n+1  -> clipped to [0, T)
+  const int n0 = qa - 1;
+  for (int fr = max(n0 - 1, 0); fr <= min(n0 + 1, g.T - 1); ++fr) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) {
+      float v[ST::EPT];
+      st.fetch(v, fb[f] + (long)fr * g.S);
+      st.store(v, s_f + ((fr % 3) * P::NF + f) * TF::SIZE);
+    }
+  }
+  if (AUX_ON) {
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x)
+      load_tile<TX, P::PER0, P::PER1, P::PER2, NT>(s_x + x * TX::SIZE, a.aux[x] + (long)b * g.S, o0, o1, o2, g, 1.0f);
+  }
+
+  // region sites of this thread: LDS offsets into the F tile / G tile, lattice flag, grid coordinates
+  int rF[RPT], rG[RPT], rX[RPT], r0[RPT], r1[RPT], r2[RPT];
+  bool rok[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int i = threadIdx.x + j * NT;
+    const int l2 = i % TG::D2 - TG::H2, rr = i / TG::D2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
+    bool ok = i < TG::SIZE;
+    const int c0 = wrap_coord<P::PER0>(o0 + l0, g.N0, ok);
+    const int c1 = wrap_coord<P::PER1>(o1 + l1, g.N1, ok);
+    const int c2 = wrap_coord<P::PER2>(o2 + l2, g.N2, ok);
+    r0[j] = c0; r1[j] = c1; r2[j] = c2;
+    rok[j] = ok && in_lattice<P>(g, c0, c1, c2);
+    rG[j] = i < TG::SIZE ? i : 0;
+    rF[j] = TF::at(l0, l1, l2);
+    rX[j] = TX::at(l0, l1, l2);
+  }
+  // output points of this thread
+  int sF[PPT], sG[PPT], sX[PPT], goff[PPT], pi0[PPT], pi1[PPT], pi2[PPT];
+  bool inside[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    int l0, l1, l2;
+    point_coords<P, TG>(p, l0, l1, l2);
+    pi0[p] = o0 + l0; pi1[p] = o1 + l1; pi2[p] = o2 + l2;
+    inside[p] = pi0[p] < g.N0 && pi1[p] < g.N1 && pi2[p] < g.N2;
+    sF[p] = TF::at(l0, l1, l2); sG[p] = TG::at(l0, l1, l2); sX[p] = TX::at(l0, l1, l2);
+    goff[p] = (pi0[p] * g.N1 + pi1[p]) * g.N2 + pi2[p];
+  }
+
+  RingAcc<P, TF, TX, 3> racc;
+  racc.cc = a.c;
+  MarchAdjAcc<P, TF, TG, TX> aacc;
+  aacc.cc = a.c;
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) { racc.spv[i] = a.sp[i][b]; aacc.spv[i] = racc.spv[i]; }
+  racc.N0 = aacc.N0 = g.N0; racc.N1 = aacc.N1 = g.N1; racc.N2 = aacc.N2 = g.N2;
+
+  float Sprev[PPT][P::NF];     // spatial adjoint of frame n-1
+  float Gm2[PPT][P::NE];       // G at the point, frame n-2
+  float Gm1[PPT][P::NE];       // G at the point, frame n-1
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) Sprev[p][f] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) { Gm2[p][k] = 0.0f; Gm1[p][k] = 0.0f; }
+  }
+  __syncthreads();
+
+  for (int n = n0; n <= qb; ++n) {
+    // prefetch F(n+2) for the next step
+    const int fnew = n + 2;
+    const bool more = n < qb && fnew < g.T;
+    float stage[P::NF][ST::EPT];
+    if (more) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
+    }
+
+    // G(n) on the tile plus the adjoint's reach
+    const bool gvalid = n >= na && n <= nb;
+    float cf[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) cf[k] = gvalid ? up[k] * a.wt[k * g.TR + (n - 1)] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      float R[P::NE];
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) R[k] = 0.0f;
+      if (gvalid && rok[j]) {
+        racc.i0 = r0[j]; racc.i1 = r1[j]; racc.i2 = r2[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) racc.fr[i] = s_f + (((n - 1 + i) % 3) * P::NF) * TF::SIZE + rF[j];
+        racc.ldsx = s_x + rX[j];
+        P::residual(racc, R);
+      }
+      if (RPT * NT == TG::SIZE || threadIdx.x + j * NT < TG::SIZE) {
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) s_g[k * TG::SIZE + rG[j]] = cf[k] * R[k];
+      }
+    }
+    __syncthreads();
+
+    const bool do_space = n >= qa && n < qb;        // frame n is an output frame of this chunk
+    const bool do_out = n - 1 >= qa && n - 1 < qb;  // frame n-1 gets completed now
+    const float* fcur = s_f + (((n + 3) % 3) * P::NF) * TF::SIZE;
+    const float* fprev = s_f + (((n + 2) % 3) * P::NF) * TF::SIZE;   // slot of frame n-1
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      float Gc[P::NE];
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) Gc[k] = s_g[k * TG::SIZE + sG[p]];
+      if (do_out && inside[p]) {
+        aacc.i0 = pi0[p]; aacc.i1 = pi1[p]; aacc.i2 = pi2[p];
+        aacc.ldsg = s_g + sG[p]; aacc.ldsf = fprev + sF[p]; aacc.ldsx = s_x + sX[p];
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) { aacc.gm[k] = Gm2[p][k]; aacc.gp[k] = Gc[k]; }
+        float gt[P::NF];
+        P::adjoint_time(aacc, gt);
+        const long o = (long)(n - 1) * g.S + goff[p];
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) a.g[f][(long)b * g.T * g.S + o] = Sprev[p][f] + gt[f];
+      }
+      float gs[P::NF];
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) gs[f] = 0.0f;
+      if (do_space && inside[p]) {
+        aacc.i0 = pi0[p]; aacc.i1 = pi1[p]; aacc.i2 = pi2[p];
+        aacc.ldsg = s_g + sG[p]; aacc.ldsf = fcur + sF[p]; aacc.ldsx = s_x + sX[p];
+        P::adjoint_space(aacc, gs);
+      }
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) Sprev[p][f] = gs[f];
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) { Gm2[p][k] = Gm1[p][k]; Gm1[p][k] = Gc[k]; }
+    }
+    __syncthreads();     // gathers are done with s_g and with the slot of frame n-1
+    if (more) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % 3) * P::NF + f) * TF::SIZE);
+      __syncthreads();
     }
   }
 }

@@ -1,13 +1,16 @@
 """Differentiable residual-loss primitive over the C ABI.
 
-`residual_sums(problem, fields, ...)` returns the fp64 tensor sums[B, n_eqs] of weighted squared
-residuals; its autograd backward launches the adjoint stencil kernel.  Everything runs on the
-current torch HIP stream; there is no host synchronisation and no CPU path.
+`residual_losses(problem, fields, weights, ...)` returns `(totals, sums)`:
+  totals  fp32 [n_eqs + 1]  per-equation losses and, last, their sum  (what the loss modules hand out)
+  sums    fp64 [B, n_eqs]   per-sample weighted squared-residual sums
+Both are differentiable w.r.t. the fields; the backward launches ONE adjoint-stencil kernel that reads
+the upstream gradients on the device (no host synchronisation, no elementwise glue kernels).
+Everything runs on the current torch HIP stream.  There is no CPU path.
 """
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -50,6 +53,9 @@ class HipBackend:
     def _stream(t: torch.Tensor):
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
+    def can_recompute(self, spec: str) -> bool:
+        return bool(_lib.pde_info(spec).can_recompute)
+
     def forward(self, prob: StencilProblem, fields, aux, sparams, weights, store_residuals: bool):
         f0 = fields[0]
         if not f0.is_cuda:
@@ -61,6 +67,7 @@ class HipBackend:
         TR = max(T - s.tlo - s.thi, 0)
         ne = len(s.eqs)
         sums = torch.empty((B, ne), dtype=torch.float64, device=f0.device)
+        totals = torch.empty((ne + 1,), dtype=torch.float32, device=f0.device)
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f0.device)
         resid = None
@@ -71,21 +78,24 @@ class HipBackend:
         with torch.cuda.device(f0.device):
             st = L.pde_amd_residual_forward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                             _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()),
-                                            C.c_void_p(sums.data_ptr()), rptr, C.c_void_p(ws.data_ptr()), ws_bytes,
-                                            self._stream(f0))
+                                            C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), rptr,
+                                            C.c_void_p(ws.data_ptr()), ws_bytes, self._stream(f0))
         _lib.check(st, f"residual_forward[{prob.spec}]")
-        return sums, resid
+        return totals, sums, resid
 
-    def backward(self, prob: StencilProblem, fields, aux, sparams, coef, resid):
+    def backward(self, prob: StencilProblem, fields, aux, sparams, weights, upstream, upstream_sums, resid):
         f0 = fields[0]
         L = _lib.lib()
+        s = SPECS[prob.spec]
         cp = prob.c_struct(f0.shape)
         grads = [torch.empty_like(f) for f in fields]
         rptr = _lib.ptr_array(resid, len(resid)) if resid is not None else None
+        uptr = _lib.ptr_array(upstream, len(s.eqs) + 1) if upstream is not None else None
+        gs = C.c_void_p(upstream_sums.data_ptr()) if upstream_sums is not None else None
         with torch.cuda.device(f0.device):
             st = L.pde_amd_residual_backward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
-                                             _lib.ptr_array(sparams, len(sparams)), C.c_void_p(coef.data_ptr()), rptr,
-                                             _lib.ptr_array(grads, len(grads)), None, 0, self._stream(f0))
+                                             _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), uptr, gs,
+                                             rptr, _lib.ptr_array(grads, len(grads)), None, 0, self._stream(f0))
         _lib.check(st, f"residual_backward[{prob.spec}]")
         return grads
 
@@ -100,30 +110,49 @@ def set_backend(b):
     return old
 
 
-class _ResidualSums(torch.autograd.Function):
+def get_backend():
+    return _BACKEND
+
+
+class _ResidualLosses(torch.autograd.Function):
+    """outputs: totals[0], ..., totals[n_eqs] as 0-dim tensors, then sums[B, n_eqs]."""
+
     @staticmethod
     def forward(ctx, prob, aux, sparams, weights, mode, *fields):
         need_grad = any(ctx.needs_input_grad[5:])
+        if mode == "auto":
+            mode = "recompute" if _BACKEND.can_recompute(prob.spec) else "stored"
         store = need_grad and mode == "stored"
-        sums, resid = _BACKEND.forward(prob, fields, aux, sparams, weights, store)
+        totals, sums, resid = _BACKEND.forward(prob, fields, aux, sparams, weights, store)
         ctx.prob, ctx.aux, ctx.sparams, ctx.weights, ctx.resid = prob, aux, sparams, weights, resid
         ctx.save_for_backward(*fields)
-        return sums
+        ctx.set_materialize_grads(False)
+        return (*totals.unbind(0), sums)
 
     @staticmethod
-    def backward(ctx, gsums):
+    def backward(ctx, *gouts):
         fields = ctx.saved_tensors
-        # d loss / d R_k(b, t, site) = gsums[b, k] * 2 * w[k, t] * R_k
-        coef = (2.0 * gsums.to(torch.float64)[:, :, None] * ctx.weights.to(torch.float64)[None]).to(torch.float32).contiguous()
-        grads = _BACKEND.backward(ctx.prob, fields, ctx.aux, ctx.sparams, coef, ctx.resid)
+        *gtot, gsums = gouts
+        ups = [g.to(torch.float32).contiguous() if g is not None else None for g in gtot]
+        if all(u is None for u in ups):
+            ups = None
+        gs = gsums.to(torch.float64).contiguous() if gsums is not None else None
+        if ups is None and gs is None:
+            return (None,) * (5 + len(fields))
+        grads = _BACKEND.backward(ctx.prob, fields, ctx.aux, ctx.sparams, ctx.weights, ups, gs, ctx.resid)
         out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:])]
         return (None, None, None, None, None, *out)
 
 
-def residual_sums(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
-                  sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = (),
-                  mode: str = "stored") -> torch.Tensor:
-    """sums[b, k] = sum_{t, site} weights[k, t] * R_k(b, t, site)^2   (fp64, differentiable w.r.t. fields)."""
+def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
+                    sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = (),
+                    mode: str = "auto"):
+    """-> (list of n_eqs + 1 scalar fp32 tensors: per-equation losses then their sum, sums[B, n_eqs] fp64).
+
+    loss_k = sum_{b, t, site} weights[k, t] * R_k(b, t, site)^2.
+    mode: 'recompute' (adjoint kernel re-evaluates the residuals; nothing is stored between forward and
+    backward), 'stored' (forward writes the residuals, backward reads them), or 'auto'.
+    """
     s = SPECS[prob.spec]
     if len(fields) != len(s.fields) or len(sparams) != len(s.sparams) or len(aux) != len(s.aux):
         raise ValueError(f"{prob.spec}: expected {len(s.fields)} fields, {len(s.sparams)} per-sample parameters, {len(s.aux)} aux fields")
@@ -138,5 +167,9 @@ def residual_sums(prob: StencilProblem, fields: Sequence[torch.Tensor], weights:
     for p in sp:
         if p.shape != (shape[0],):
             raise ValueError(f"{prob.spec}: per-sample parameters must have shape [{shape[0]}], got {tuple(p.shape)}")
+    for x in ax:
+        if tuple(x.shape) != (shape[0],) + tuple(shape[2:]):
+            raise ValueError(f"{prob.spec}: auxiliary fields must be [B, *spatial], got {tuple(x.shape)}")
     w = weights.to(device=fs[0].device, dtype=torch.float32).contiguous()
-    return _ResidualSums.apply(prob, tuple(ax), tuple(sp), w, mode, *fs)
+    out = _ResidualLosses.apply(prob, tuple(ax), tuple(sp), w, mode, *fs)
+    return list(out[:-1]), out[-1]

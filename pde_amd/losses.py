@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functional import StencilProblem, residual_sums
+from .functional import StencilProblem, residual_losses
 from .stencil.specs import SPECS
 
 Tensor = torch.Tensor
@@ -34,7 +34,7 @@ class StencilPDELoss(nn.Module):
     PER_T_ALIAS: Dict[str, str] = {}        # equation -> buffer suffix when they differ
     TOTAL_KEY: bool = False                 # whether the dict carries 'total'
     SCALE_KEYS: Dict[str, str] = {}         # equation -> key looked up in eq_scales / eq_weights when they differ
-    backward_mode = "stored"
+    backward_mode = "auto"                  # 'recompute' | 'stored' | 'auto' (recompute where the PDE supports it)
 
     def _init_common(self, default_scales, eq_scales, eq_weights, eq_scales_per_t, per_t_supported=True):
         self.eq_scales = {**default_scales, **(eq_scales or {})}
@@ -138,20 +138,28 @@ class StencilPDELoss(nn.Module):
         T_res = T - spec.tlo - spec.thi
         n_sites = B * max(T_res, 0) * ext[0] * ext[1] * ext[2]
         wt, skipped = self._weights(T_res, n_sites, f0.device, t_offset)
-        sums = residual_sums(prob, fields, wt, sparams, aux, mode=self.backward_mode)   # [B, n_eqs] fp64
-        per_eq = sums.sum(dim=0).to(torch.float32)
+        totals, sums = residual_losses(prob, fields, wt, sparams, aux, mode=self.backward_mode)
+        self.last_per_sample = sums.detach()        # [B, n_eqs] fp64 diagnostic: each sample's share of every loss
         losses: Dict[str, Tensor] = {}
+        all_kept = not any(skipped) and n_sites > 0
         for k, eq in enumerate(self.EQS):
             if skipped[k]:
-                losses[eq] = torch.tensor(0.0, device=f0.device)
+                losses[eq] = self._zero(f0.device)
             elif n_sites == 0:
-                losses[eq] = per_eq[k] * float("nan")      # mean over an empty lattice
+                losses[eq] = totals[k] * float("nan")      # mean over an empty lattice
             else:
-                losses[eq] = per_eq[k]
-        total = sum(losses.values())
+                losses[eq] = totals[k]
+        # the kernel's fp32 left-to-right sum is the reference's sum(losses.values()) when nothing was skipped
+        total = totals[-1] if all_kept else sum(losses.values())
         if self.TOTAL_KEY:
             losses["total"] = total
         return total, losses
+
+    def _zero(self, device) -> Tensor:
+        key = ("zero", str(device))
+        if key not in self._wt_cache:
+            self._wt_cache[key] = torch.zeros((), dtype=torch.float32, device=device)
+        return self._wt_cache[key]
 
 
 # =================================================================================================
@@ -698,7 +706,7 @@ def burgers_pde_loss(pred: Tensor, nu: float, dt: float = 1 / 999, dx: float = 1
 
     pred is channel-last [B, T, H, W, 2]; residuals are [B, T-1, H-2, W-2] (detached: they are diagnostics).
     """
-    from .functional import _BACKEND  # late: tests may swap it
+    from .functional import get_backend  # late: tests may swap it
     B, T, H, W, C2 = pred.shape
     assert T >= 2, "T must be at least 2"
     assert H >= 4 and W >= 4, "H, W must be at least 4"
@@ -708,14 +716,13 @@ def burgers_pde_loss(pred: Tensor, nu: float, dt: float = 1 / 999, dx: float = 1
     prob = StencilProblem("burgers2d_ghost", [fn(p) for _, fn in spec.consts], (0, 1, 1), (0, 1, 1))
     n = B * (T - 1) * (H - 2) * (W - 2)
     wt = torch.full((2, T - 1), 1.0 / n, dtype=torch.float32, device=pred.device)
-    sums = residual_sums(prob, [u, v], wt, mode="stored")
-    per_eq = sums.sum(dim=0).to(torch.float32)
-    loss_u, loss_v = per_eq[0], per_eq[1]
+    totals, _ = residual_losses(prob, [u, v], wt, mode="stored")
+    loss_u, loss_v = totals[0], totals[1]
     with torch.no_grad():
         fs = [u.detach().float().contiguous(), v.detach().float().contiguous()]
-        _, resid = _BACKEND.forward(prob, fs, (), (), wt, True)
+        _, _, resid = get_backend().forward(prob, fs, (), (), wt, True)
     ru, rv = (r[:, :, 1:H - 1, 1:W - 1] for r in resid)
-    return loss_u + loss_v, loss_u, loss_v, ru, rv
+    return totals[2], loss_u, loss_v, ru, rv
 
 
 burgers_pde_loss_upwind = burgers_pde_loss

@@ -128,6 +128,9 @@ class InterpBackend:
             R = [np.where(mask, np.broadcast_to(env.ev(r), env.shape), 0.0) for r in s.residuals]
         return s, F, A, SP, C, R, TR
 
+    def can_recompute(self, spec):
+        return True
+
     def forward(self, prob, fields, aux, sparams, weights, store):
         s, F, A, SP, C, R, TR = self._residuals(prob, fields, aux, sparams)
         w = weights.detach().cpu().double().numpy()
@@ -139,12 +142,26 @@ class InterpBackend:
         resid = None
         if store:
             resid = [torch.tensor(r.reshape((B, TR) + tuple(fields[0].shape[2:])), dtype=torch.float32, device=dev) for r in R]
-        return torch.tensor(sums, dtype=torch.float64, device=dev), resid
+        per_eq = sums.sum(0).astype(np.float32)
+        tot = np.float32(0.0)
+        for v in per_eq:
+            tot = np.float32(tot + v)
+        totals = torch.tensor(np.concatenate([per_eq, [tot]]), dtype=torch.float32, device=dev)
+        return totals, torch.tensor(sums, dtype=torch.float64, device=dev), resid
 
-    def backward(self, prob, fields, aux, sparams, coef, resid):
+    def backward(self, prob, fields, aux, sparams, weights, upstream, upstream_sums, resid):
         s, F, A, SP, C, R, TR = self._residuals(prob, fields, aux, sparams)
-        cf = coef.detach().cpu().double().numpy()       # [B, NE, TR]
         B, T = F[0].shape[:2]
+        ne = len(s.eqs)
+        w = weights.detach().cpu().double().numpy()          # [NE, TR]
+        u = np.zeros((B, ne))
+        if upstream is not None:
+            gt = float(upstream[ne]) if upstream[ne] is not None else 0.0
+            for k in range(ne):
+                u[:, k] += gt + (float(upstream[k]) if upstream[k] is not None else 0.0)
+        if upstream_sums is not None:
+            u += upstream_sums.detach().cpu().double().numpy()
+        cf = 2.0 * u[:, :, None] * w[None]                   # [B, NE, TR]
         sp_shape = F[0].shape[2:]
         # G_k on every frame (zero outside the residual frames)
         G = []

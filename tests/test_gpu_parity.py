@@ -31,11 +31,13 @@ def _run(mod, fields, extra):
     return total, losses, [f.grad for f in fields]
 
 
+@pytest.mark.parametrize("mode", ["auto", "stored"])
 @pytest.mark.parametrize("name", golden_cases())
-def test_golden(name):
+def test_golden(name, mode):
     dev = _dev()
     meta, kwargs, fields, extra, z = load_case(name, torch.float32, dev)
     mod = getattr(PL, meta["cls"])(**kwargs).to(dev)
+    mod.backward_mode = mode
     total, losses, grads = _run(mod, fields, extra)
     ref_total = float(z["f64_total"])
     assert abs(float(total) - ref_total) <= TOL * abs(ref_total)
@@ -81,8 +83,9 @@ SIZED = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["auto", "stored"])
 @pytest.mark.parametrize("cls,kw,shape,ps", SIZED, ids=[s[0] for s in SIZED])
-def test_ragged_sizes_vs_oracle(cls, kw, shape, ps):
+def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
     dev = _dev()
     g = torch.Generator().manual_seed(11)
     spec = PL.SPECS[getattr(PL, cls).SPEC] if getattr(PL, cls).SPEC else PL.SPECS["gray_scott_pw"]
@@ -92,6 +95,7 @@ def test_ragged_sizes_vs_oracle(cls, kw, shape, ps):
         fields[2] = fields[2].abs() + 0.5
     extra = {k: lo + (hi - lo) * torch.rand(shape[0], generator=g) for k, (lo, hi) in ps.items()}
     mod = getattr(PL, cls)(**kw).to(dev)
+    mod.backward_mode = mode
     total, losses, grads = _run(mod, [f.to(dev) for f in fields], {k: v.to(dev) for k, v in extra.items()})
     f64 = [f.double().requires_grad_(True) for f in fields]
     ot, ol = OC.build(cls, **kw)(*f64, **{k: v.double() for k, v in extra.items()})
@@ -130,3 +134,47 @@ def test_two_frames_gives_empty_lattice():
     mod = PL.Heat1DPDELoss().to(dev)
     total, _ = mod(torch.randn(2, 2, 64, device=dev), torch.tensor([0.01, 0.02], device=dev))
     assert torch.isnan(total)      # mean over an empty residual lattice, as in the reference
+
+
+def test_upstream_gradients_and_long_clips():
+    """lambda * total plus a separately weighted equation loss; T long enough for several marching chunks."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    shape = (1, 23, 20, 70)
+    fields = [torch.randn(shape, generator=g) * 0.5 for _ in range(3)]
+    kw = dict(nx=70, ny=20, dt=0.01, eq_scales={"continuity": 0.5, "x_momentum": 2.0, "y_momentum": 3.0})
+    nu = torch.tensor([0.03])
+    for mode in ("auto", "stored"):
+        mod = PL.TaylorGreen2DPDELoss(**kw).to(dev)
+        mod.backward_mode = mode
+        df = [f.to(dev).requires_grad_(True) for f in fields]
+        total, losses = mod(*df, nu=nu.to(dev))
+        (0.37 * total + 2.5 * losses["x_momentum"]).backward()
+        f64 = [f.double().requires_grad_(True) for f in fields]
+        ot, ol = OC.build("TaylorGreen2DPDELoss", **kw)(*f64, nu=nu.double())
+        (0.37 * ot + 2.5 * ol["x_momentum"]).backward()
+        for a, b in zip(df, f64):
+            assert rel_l2(a.grad.cpu().numpy(), b.grad.numpy()) <= TOL, mode
+
+
+def test_per_sample_sums_are_differentiable():
+    dev = _dev()
+    g = torch.Generator().manual_seed(22)
+    u = (torch.randn(3, 6, 300, generator=g) * 0.5)
+    nu = torch.tensor([0.01, 0.02, 0.03])
+    from pde_amd.functional import StencilProblem, residual_losses
+    spec = PL.SPECS["burgers1d"]
+    p = dict(dx=0.02, dt=0.01)
+    prob = StencilProblem("burgers1d", [fn(p) for _, fn in spec.consts])
+    wt = torch.full((1, 4), 1.0 / (3 * 4 * 300), device=dev)
+    ud = u.to(dev).requires_grad_(True)
+    totals, sums = residual_losses(prob, [ud], wt, [nu.to(dev)])
+    coeff = torch.tensor([[1.0], [-2.0], [0.5]], dtype=torch.float64, device=dev)
+    (sums * coeff).sum().backward()
+    u64 = u.double().requires_grad_(True)
+    from oracle import pde_oracle as O
+    R = O.residuals_burgers1d(u64, nu.double(), dx=0.02, dt=0.01)[0]
+    per = (R ** 2).sum(dim=(1, 2)) / (3 * 4 * 300)
+    (per * coeff.cpu().view(-1)).sum().backward()
+    assert rel_l2(ud.grad.cpu().numpy(), u64.grad.numpy()) <= TOL
+    assert rel_l2(sums.detach().cpu().numpy().ravel(), per.detach().numpy()) <= TOL
