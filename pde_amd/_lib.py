@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares libamdhip64 with the extension)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpde_amd.so")
+LIB_PATH = os.environ.get("PDE_AMD_LIB", os.path.join(_HERE, "libpde_amd.so"))   # override: A/B builds while tuning
 
 MAX_FIELDS, MAX_EQS, MAX_AUX, MAX_SPARAMS, MAX_CONSTS = 4, 4, 1, 3, 16
 

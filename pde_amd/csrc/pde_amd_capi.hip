@@ -112,7 +112,7 @@ struct Ops {
       a.chunk = pick_chunk(p->batch * tiles, (int)tr);
       items = cdiv((int)tr, a.chunk) * tiles;
       if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
-      hipLaunchKernelGGL((fwd_march_kernel<P>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
+      hipLaunchKernelGGL((fwd_march_kernel<P>), dim3((unsigned)(p->batch * items)), dim3(P::NTM), 0, stream, a);
     } else {
       items = tr * tiles;
       if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
@@ -162,7 +162,7 @@ struct Ops {
         a.chunk = pick_chunk(p->batch * tiles, p->frames);
         const long nwg = (long)p->batch * cdiv(p->frames, a.chunk) * tiles;
         if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
-        hipLaunchKernelGGL((bwd_march_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+        hipLaunchKernelGGL((bwd_march_kernel<P>), dim3((unsigned)nwg), dim3(P::NTM), 0, stream, a);
       } else {
         return PDE_AMD_EINVAL;   // this PDE has no recomputing adjoint: pass the stored residuals
       }

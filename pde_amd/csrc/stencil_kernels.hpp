@@ -202,10 +202,10 @@ __device__ __forceinline__ void block_sum_store(const double (&acc)[NE], double*
   }
 }
 
-template <class P, class TL>
+template <class P, class TL, int NT = P::NT>
 __device__ __forceinline__ void point_coords(int k, int& l0, int& l1, int& l2) {
   // a thread owns PPT consecutive rows of one tile column
-  constexpr int PPT = (TL::T0 * TL::T1 * TL::T2) / P::NT;
+  constexpr int PPT = (TL::T0 * TL::T1 * TL::T2) / NT;
   const int row = (threadIdx.x / TL::T2) * PPT + k;
   l2 = threadIdx.x % TL::T2;
   l1 = row % TL::T1;
@@ -544,12 +544,12 @@ struct RingAcc : SiteBase<P> {
 // forward, marching: workgroup = (sample, chunk of residual frames, tile)
 // ------------------------------------------------------------------------------------------------
 template <class P>
-__global__ __launch_bounds__(P::NT) void fwd_march_kernel(const Args a) {
+__global__ __launch_bounds__(P::NTM) void fwd_march_kernel(const Args a) {
   using TL = Tile<P::FT0, P::FT1, P::FT2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), cmax(P::RH2, P::RT2)>;
   using TX = Tile<P::FT0, P::FT1, P::FT2, P::XH0, P::XH1, P::XH2>;
   constexpr int NS = P::TLO + P::THI + 1;
   constexpr bool AUX_ON = P::NA > 0;
-  constexpr int NT = P::NT;
+  constexpr int NT = P::NTM;
   constexpr int PPT = (TL::T0 * TL::T1 * TL::T2) / NT;
   using ST = Stager<TL, P::PER0, P::PER1, P::PER2, NT>;
   static_assert(PPT * NT == TL::T0 * TL::T1 * TL::T2, "tile must be a multiple of the workgroup");
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(P::NT) void fwd_march_kernel(const Args a) {
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
     int l0, l1, l2;
-    point_coords<P, TL>(p, l0, l1, l2);
+    point_coords<P, TL, NT>(p, l0, l1, l2);
     pi0[p] = o0 + l0; pi1[p] = o1 + l1; pi2[p] = o2 + l2;
     site[p] = TL::at(l0, l1, l2);
     tsite[p] = TX::at(l0, l1, l2);
@@ -627,17 +627,19 @@ __global__ __launch_bounds__(P::NT) void fwd_march_kernel(const Args a) {
     float wk[P::NE];
 #pragma unroll
     for (int k = 0; k < P::NE; ++k) wk[k] = a.wt[k * g.TR + (tau - P::TLO)];
+    // every owned point is evaluated (all LDS addresses are valid); points outside the lattice add zero
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
-      if (active[p]) {
-        acc.i0 = pi0[p]; acc.i1 = pi1[p]; acc.i2 = pi2[p];
+      acc.i0 = pi0[p]; acc.i1 = pi1[p]; acc.i2 = pi2[p];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) acc.fr[i] = s_f + (((tau - P::TLO + i) % NS) * P::NF) * TL::SIZE + site[p];
-        acc.ldsx = s_x + tsite[p];
-        float R[P::NE];
-        P::residual(acc, R);
+      for (int i = 0; i < NS; ++i) acc.fr[i] = s_f + (((tau - P::TLO + i) % NS) * P::NF) * TL::SIZE + site[p];
+      acc.ldsx = s_x + tsite[p];
+      float R[P::NE];
+      P::residual(acc, R);
 #pragma unroll
-        for (int k = 0; k < P::NE; ++k) sum[k] += (double)(R[k] * R[k]) * (double)wk[k];
+      for (int k = 0; k < P::NE; ++k) {
+        const float r = active[p] ? R[k] : 0.0f;
+        sum[k] += (double)(r * r) * (double)wk[k];
       }
     }
     if (more) {
@@ -706,13 +708,13 @@ struct FwdMarchFits {
 };
 
 template <class P>
-__global__ __launch_bounds__(P::NT) void bwd_march_kernel(const Args a) {
+__global__ __launch_bounds__(P::NTM, P::WPS) void bwd_march_kernel(const Args a) {
   constexpr int HB0 = cmax(P::GH0 + P::RH0, P::AH0), HB1 = cmax(P::GH1 + P::RH1, P::AH1), HB2 = cmax(P::GH2 + P::RH2, P::AH2);
   using TF = Tile<P::BT0, P::BT1, P::BT2, HB0, HB1, HB2>;
   using TG = Tile<P::BT0, P::BT1, P::BT2, P::GH0, P::GH1, P::GH2>;
   using TX = Tile<P::BT0, P::BT1, P::BT2, cmax(P::XH0, P::GH0), cmax(P::XH1, P::GH1), cmax(P::XH2, P::GH2)>;
   constexpr bool AUX_ON = P::NA > 0;
-  constexpr int NT = P::NT;
+  constexpr int NT = P::NTM;
   constexpr int PPT = (TG::T0 * TG::T1 * TG::T2) / NT;
   constexpr int RPT = (TG::SIZE + NT - 1) / NT;      // region sites (tile + adjoint reach) per thread
   using ST = Stager<TF, P::PER0, P::PER1, P::PER2, NT>;
@@ -764,15 +766,16 @@ __global__ __launch_bounds__(P::NT) void bwd_march_kernel(const Args a) {
   bool rok[RPT];
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int i = threadIdx.x + j * NT;
+    const int iraw = threadIdx.x + j * NT;
+    const int i = iraw < TG::SIZE ? iraw : 0;     // surplus entries of the last round alias site 0 and store nothing
     const int l2 = i % TG::D2 - TG::H2, rr = i / TG::D2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
-    bool ok = i < TG::SIZE;
+    bool ok = iraw < TG::SIZE;
     const int c0 = wrap_coord<P::PER0>(o0 + l0, g.N0, ok);
     const int c1 = wrap_coord<P::PER1>(o1 + l1, g.N1, ok);
     const int c2 = wrap_coord<P::PER2>(o2 + l2, g.N2, ok);
     r0[j] = c0; r1[j] = c1; r2[j] = c2;
     rok[j] = ok && in_lattice<P>(g, c0, c1, c2);
-    rG[j] = i < TG::SIZE ? i : 0;
+    rG[j] = i;
     rF[j] = TF::at(l0, l1, l2);
     rX[j] = TX::at(l0, l1, l2);
   }
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(P::NT) void bwd_march_kernel(const Args a) {
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
     int l0, l1, l2;
-    point_coords<P, TG>(p, l0, l1, l2);
+    point_coords<P, TG, NT>(p, l0, l1, l2);
     pi0[p] = o0 + l0; pi1[p] = o1 + l1; pi2[p] = o2 + l2;
     inside[p] = pi0[p] < g.N0 && pi1[p] < g.N1 && pi2[p] < g.N2;
     sF[p] = TF::at(l0, l1, l2); sG[p] = TG::at(l0, l1, l2); sX[p] = TX::at(l0, l1, l2);
@@ -829,16 +832,17 @@ __global__ __launch_bounds__(P::NT) void bwd_march_kernel(const Args a) {
       float R[P::NE];
 #pragma unroll
       for (int k = 0; k < P::NE; ++k) R[k] = 0.0f;
-      if (gvalid && rok[j]) {
+      // uniform in gvalid; in the last round only the waves that still own sites take part
+      if (gvalid && (RPT * NT == TG::SIZE || j < RPT - 1 || threadIdx.x + j * NT < TG::SIZE)) {
         racc.i0 = r0[j]; racc.i1 = r1[j]; racc.i2 = r2[j];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) racc.fr[i] = s_f + (((n - 1 + i) % 3) * P::NF) * TF::SIZE + rF[j];
+        for (int i = 0; i < 3; ++i) racc.fr[i] = s_f + (((n + 2 + i) % 3) * P::NF) * TF::SIZE + rF[j];
         racc.ldsx = s_x + rX[j];
         P::residual(racc, R);
       }
       if (RPT * NT == TG::SIZE || threadIdx.x + j * NT < TG::SIZE) {
 #pragma unroll
-        for (int k = 0; k < P::NE; ++k) s_g[k * TG::SIZE + rG[j]] = cf[k] * R[k];
+        for (int k = 0; k < P::NE; ++k) s_g[k * TG::SIZE + rG[j]] = rok[j] ? cf[k] * R[k] : 0.0f;
       }
     }
     __syncthreads();
@@ -852,23 +856,25 @@ __global__ __launch_bounds__(P::NT) void bwd_march_kernel(const Args a) {
       float Gc[P::NE];
 #pragma unroll
       for (int k = 0; k < P::NE; ++k) Gc[k] = s_g[k * TG::SIZE + sG[p]];
-      if (do_out && inside[p]) {
-        aacc.i0 = pi0[p]; aacc.i1 = pi1[p]; aacc.i2 = pi2[p];
-        aacc.ldsg = s_g + sG[p]; aacc.ldsf = fprev + sF[p]; aacc.ldsx = s_x + sX[p];
+      aacc.i0 = pi0[p]; aacc.i1 = pi1[p]; aacc.i2 = pi2[p];
+      aacc.ldsg = s_g + sG[p]; aacc.ldsx = s_x + sX[p];
+      if (do_out) {      // uniform
+        aacc.ldsf = fprev + sF[p];
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) { aacc.gm[k] = Gm2[p][k]; aacc.gp[k] = Gc[k]; }
         float gt[P::NF];
         P::adjoint_time(aacc, gt);
-        const long o = (long)(n - 1) * g.S + goff[p];
+        if (inside[p]) {
+          const long o = (long)(n - 1) * g.S + goff[p];
 #pragma unroll
-        for (int f = 0; f < P::NF; ++f) a.g[f][(long)b * g.T * g.S + o] = Sprev[p][f] + gt[f];
+          for (int f = 0; f < P::NF; ++f) a.g[f][(long)b * g.T * g.S + o] = Sprev[p][f] + gt[f];
+        }
       }
       float gs[P::NF];
 #pragma unroll
       for (int f = 0; f < P::NF; ++f) gs[f] = 0.0f;
-      if (do_space && inside[p]) {
-        aacc.i0 = pi0[p]; aacc.i1 = pi1[p]; aacc.i2 = pi2[p];
-        aacc.ldsg = s_g + sG[p]; aacc.ldsf = fcur + sF[p]; aacc.ldsx = s_x + sX[p];
+      if (do_space) {    // uniform
+        aacc.ldsf = fcur + sF[p];
         P::adjoint_space(aacc, gs);
       }
 #pragma unroll

@@ -35,7 +35,9 @@ class Spec:
     # tile shapes (axis0, axis1, axis2) and threads for the kernels
     tile_fwd: Tuple[int, int, int] = (1, 16, 64)
     tile_bwd: Tuple[int, int, int] = (1, 16, 64)
-    threads: int = 256
+    threads: int = 256           # workgroup size of the per-frame kernels
+    threads_march: int = 256     # workgroup size of the time-marching kernels
+    waves_per_simd: int = 2      # occupancy the marching adjoint is compiled for (__launch_bounds__ 2nd argument)
 
     # derived
     def analyse(self):
@@ -177,7 +179,7 @@ def _tg2d():
     cont = dx(u) + dy(v)
     xm = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - nu * lap(u)
     ym = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - nu * lap(v)
-    return b.done([cont, xm, ym])
+    return b.done([cont, xm, ym], threads_march=512, waves_per_simd=4)
 
 
 def _advdiff2d():
