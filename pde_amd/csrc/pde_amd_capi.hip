@@ -1,6 +1,7 @@
 // C ABI (include/pde_amd.h) over the stencil kernels: validation, geometry, kernel choice, launches.
 #include "../../include/pde_amd.h"
 #include "stencil_kernels.hpp"
+#include "stencil_quad.hpp"
 #include <string.h>
 
 namespace pde_amd {
@@ -19,6 +20,15 @@ struct PdeVTable {
 };
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// The register-blocked kernels move 16 bytes per lane: every pointer must be 16-byte aligned and the
+// fastest extent a multiple of 4.
+template <int N>
+static inline bool aligned16(const float* const* p) {
+  for (int i = 0; i < N; ++i)
+    if (reinterpret_cast<uintptr_t>(p[i]) & 15) return false;
+  return true;
+}
 static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 // Frames per marching workgroup: whole clips when samples x tiles already fill the chip, shorter chunks
@@ -99,7 +109,7 @@ struct Ops {
     a.wt = weights;
     a.partial = reinterpret_cast<double*>(ws);
     const long tiles = fwd_tiles(p);
-    long items;   // partial sums per sample
+    long items = 0;   // partial sums per sample
     if (resid_out) {
       for (int k = 0; k < P::NE; ++k) {
         if (!resid_out[k]) return PDE_AMD_EINVAL;
@@ -108,6 +118,15 @@ struct Ops {
       items = tr * tiles;
       if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
       hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
+    } else if (QuadCfg<P>::FWD_OK && p->n[2] % 4 == 0 && aligned16<P::NF>(fields) && (!P::NA || aligned16<P::NA>(aux))) {
+      if constexpr (QuadCfg<P>::FWD_OK) {
+        fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
+        const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+        a.chunk = pick_chunk(p->batch * qtiles, (int)tr);
+        items = cdiv((int)tr, a.chunk) * qtiles;
+        if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+        hipLaunchKernelGGL((fwd_march_q_kernel<P>), dim3((unsigned)(p->batch * items)), dim3(P::NTQ), 0, stream, a);
+      }
     } else if constexpr (FwdMarchFits<P>::value) {
       a.chunk = pick_chunk(p->batch * tiles, (int)tr);
       items = cdiv((int)tr, a.chunk) * tiles;
@@ -145,6 +164,9 @@ struct Ops {
     fill_geom(p, a.geo, P::BT0, P::BT1, P::BT2);
     a.wt = weights;
     a.gsums = upstream_sums;
+#ifdef PDE_AMD_STAMPS
+    a.partial = reinterpret_cast<double*>(ws);
+#endif
     if (upstream)
       for (int k = 0; k <= P::NE; ++k) a.ups[k] = upstream[k];
     for (int f = 0; f < P::NF; ++f) a.g[f] = grads[f];
@@ -157,6 +179,16 @@ struct Ops {
       const long nwg = (long)p->batch * p->frames * tiles;
       if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
       hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+    } else if (QuadCfg<P>::BWD_OK && p->n[2] % 4 == 0 && aligned16<P::NF>(fields) && aligned16<P::NF>(grads) &&
+               (!P::NA || aligned16<P::NA>(aux))) {
+      if constexpr (QuadCfg<P>::BWD_OK) {
+        fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);
+        const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+        a.chunk = pick_chunk(p->batch * qtiles, p->frames);
+        const long nwg = (long)p->batch * cdiv(p->frames, a.chunk) * qtiles;
+        if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+        hipLaunchKernelGGL((bwd_march_q_kernel<P>), dim3((unsigned)nwg), dim3(P::NTQ), 0, stream, a);
+      }
     } else {
       if constexpr (BwdMarchFits<P>::value) {
         a.chunk = pick_chunk(p->batch * tiles, p->frames);
@@ -177,7 +209,7 @@ struct Ops {
     v.info.halo[0] = P::RH0 > P::RT0 ? P::RH0 : P::RT0;
     v.info.halo[1] = P::RH1 > P::RT1 ? P::RH1 : P::RT1;
     v.info.halo[2] = P::RH2 > P::RT2 ? P::RH2 : P::RT2;
-    v.info.can_recompute = BwdMarchFits<P>::value ? 1 : 0;
+    v.info.can_recompute = BwdMarchFits<P>::value ? 1 : 0;   // the quad adjoint is an accelerated form of the same mode
     v.info.name = P::NAME;
     v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd;
     return v;

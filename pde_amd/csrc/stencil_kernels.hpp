@@ -44,6 +44,14 @@ struct Args {
   Geom geo;
 };
 
+// Uniform read of a small read-only table (weights, per-sample parameters, upstream gradients) through the
+// constant address space: the compiler may then use scalar loads, whose waits (lgkmcnt) do not get
+// entangled with the vector-memory counter that the frame prefetch relies on.
+typedef const float __attribute__((address_space(4))) * cfloat_ptr;
+typedef const double __attribute__((address_space(4))) * cdouble_ptr;
+__device__ __forceinline__ float ldc(const float* p, long i) { return ((cfloat_ptr)(uintptr_t)p)[i]; }
+__device__ __forceinline__ double ldc(const double* p, long i) { return ((cdouble_ptr)(uintptr_t)p)[i]; }
+
 // ------------------------------------------------------------------------------------------------
 // tiles
 // ------------------------------------------------------------------------------------------------
@@ -220,11 +228,11 @@ __device__ __forceinline__ bool in_lattice(const Geom& g, int i0, int i1, int i2
 // G_k = coef * R_k with coef = 2 * weight[k][frame] * (dL/dloss_k + dL/dtotal) + 2 * weight * dL/dsums[b][k]
 template <class P>
 __device__ __forceinline__ void upstream_of(const Args& a, int b, float (&up)[P::NE]) {
-  const float gt = a.ups[P::NE] ? *a.ups[P::NE] : 0.0f;
+  const float gt = a.ups[P::NE] ? ldc(a.ups[P::NE], 0) : 0.0f;
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) {
-    float u = gt + (a.ups[k] ? *a.ups[k] : 0.0f);
-    if (a.gsums) u += (float)a.gsums[(long)b * P::NE + k];
+    float u = gt + (a.ups[k] ? ldc(a.ups[k], 0) : 0.0f);
+    if (a.gsums) u += (float)ldc(a.gsums, (long)b * P::NE + k);
     up[k] = 2.0f * u;
   }
 }
@@ -281,14 +289,14 @@ __global__ __launch_bounds__(P::NT) void fwd_kernel(const Args a) {
   ResAcc<P, TL, TT, TX> acc;
   acc.cc = a.c;
 #pragma unroll
-  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = a.sp[i][b];
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = ldc(a.sp[i], b);
 #pragma unroll
   for (int f = 0; f < P::NF; ++f) acc.fp[f] = a.f[f] + frame;
   acc.S = g.S; acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
 
   float wk[P::NE];
 #pragma unroll
-  for (int k = 0; k < P::NE; ++k) wk[k] = a.wt[k * g.TR + tr];
+  for (int k = 0; k < P::NE; ++k) wk[k] = ldc(a.wt, k * g.TR + tr);
 
   double sum[P::NE];
 #pragma unroll
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(P::NT) void bwd_stored_kernel(const Args a) {
   AdjAcc<P, TG, TGT, TA, TAT, TX> acc;
   acc.cc = a.c;
 #pragma unroll
-  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = a.sp[i][b];
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = ldc(a.sp[i], b);
 #pragma unroll
   for (int f = 0; f < P::NF; ++f) acc.fp[f] = a.f[f] + frame;
 #pragma unroll
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(P::NT) void bwd_stored_kernel(const Args a) {
     const int trs = tq + (s - P::GTLO) - P::TLO;
     const bool ok = trs >= 0 && trs < g.TR;
 #pragma unroll
-    for (int k = 0; k < P::NE; ++k) acc.cf[s][k] = ok ? up[k] * a.wt[k * g.TR + trs] : 0.0f;
+    for (int k = 0; k < P::NE; ++k) acc.cf[s][k] = ok ? up[k] * ldc(a.wt, k * g.TR + trs) : 0.0f;
   }
 
 #pragma unroll
@@ -515,13 +523,14 @@ struct Stager {
   }
   __device__ __forceinline__ void fetch(float (&v)[EPT], const float* __restrict__ frame) const {
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) v[j] = off[j] >= 0 ? frame[off[j]] : 0.0f;
+    // always a valid address, and no use of the result here: the loads stay in flight until store()
+    for (int j = 0; j < EPT; ++j) v[j] = frame[max(off[j], 0)];
   }
   __device__ __forceinline__ void store(const float (&v)[EPT], float* __restrict__ tile) const {
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       const int i = threadIdx.x + j * NT;
-      if (EPT * NT == TL::SIZE || i < TL::SIZE) tile[i] = v[j];
+      if (EPT * NT == TL::SIZE || i < TL::SIZE) tile[i] = off[j] >= 0 ? v[j] : 0.0f;   // wall-side points read 0
     }
   }
 };
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(P::NTM) void fwd_march_kernel(const Args a) {
   RingAcc<P, TL, TX, NS> acc;
   acc.cc = a.c;
 #pragma unroll
-  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = a.sp[i][b];
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = ldc(a.sp[i], b);
   acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
 
   // the points this thread owns
@@ -614,6 +623,10 @@ __global__ __launch_bounds__(P::NTM) void fwd_march_kernel(const Args a) {
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) sum[k] = 0.0;
 
+  float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + (ra - P::TLO));
+
   for (int tau = ra; tau < rb; ++tau) {
     // fetch the frame the NEXT step adds while this step computes; it replaces the oldest frame afterwards
     const bool more = tau + 1 < rb;
@@ -626,7 +639,10 @@ __global__ __launch_bounds__(P::NTM) void fwd_march_kernel(const Args a) {
 
     float wk[P::NE];
 #pragma unroll
-    for (int k = 0; k < P::NE; ++k) wk[k] = a.wt[k * g.TR + (tau - P::TLO)];
+    for (int k = 0; k < P::NE; ++k) {
+      wk[k] = wnext[k];
+      wnext[k] = ldc(a.wt, k * g.TR + min(tau + 1 - P::TLO, g.TR - 1));
+    }
     // every owned point is evaluated (all LDS addresses are valid); points outside the lattice add zero
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
@@ -797,7 +813,7 @@ __global__ __launch_bounds__(P::NTM, P::WPS) void bwd_march_kernel(const Args a)
   MarchAdjAcc<P, TF, TG, TX> aacc;
   aacc.cc = a.c;
 #pragma unroll
-  for (int i = 0; i < P::NSP; ++i) { racc.spv[i] = a.sp[i][b]; aacc.spv[i] = racc.spv[i]; }
+  for (int i = 0; i < P::NSP; ++i) { racc.spv[i] = ldc(a.sp[i], b); aacc.spv[i] = racc.spv[i]; }
   racc.N0 = aacc.N0 = g.N0; racc.N1 = aacc.N1 = g.N1; racc.N2 = aacc.N2 = g.N2;
 
   float Sprev[PPT][P::NF];     // spatial adjoint of frame n-1
@@ -811,6 +827,10 @@ __global__ __launch_bounds__(P::NTM, P::WPS) void bwd_march_kernel(const Args a)
     for (int k = 0; k < P::NE; ++k) { Gm2[p][k] = 0.0f; Gm1[p][k] = 0.0f; }
   }
   __syncthreads();
+
+  float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + min(max(n0 - 1, 0), g.TR - 1));
 
   for (int n = n0; n <= qb; ++n) {
     // prefetch F(n+2) for the next step
@@ -826,7 +846,10 @@ __global__ __launch_bounds__(P::NTM, P::WPS) void bwd_march_kernel(const Args a)
     const bool gvalid = n >= na && n <= nb;
     float cf[P::NE];
 #pragma unroll
-    for (int k = 0; k < P::NE; ++k) cf[k] = gvalid ? up[k] * a.wt[k * g.TR + (n - 1)] : 0.0f;
+    for (int k = 0; k < P::NE; ++k) {
+      cf[k] = gvalid ? up[k] * wnext[k] : 0.0f;
+      wnext[k] = ldc(a.wt, k * g.TR + min(max(n, 0), g.TR - 1));
+    }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       float R[P::NE];

@@ -1,0 +1,548 @@
+// Time-marching kernels, register-blocked along the fastest axis ("quad" kernels).
+//
+// A lane owns 4 consecutive points of a row.  Global loads and stores are 16 bytes per lane, LDS tiles
+// are read as aligned float4 (ds_read_b128: twice the bytes per LDS cycle of dword reads, a quarter of
+// the instructions), and the +-1..4 neighbours along the row come out of the lane's own registers.
+// The generated residual / adjoint code is unchanged: it is evaluated once per point with the point's
+// position inside the quad (`px`) known at compile time, so every stencil reference folds to
+// "element e of the float4 at compile-time offset d", and identical float4 loads are merged.
+//
+// Requirements (checked on the host, else the dword kernels of stencil_kernels.hpp run): the fastest
+// extent is a multiple of 4 and every field pointer is 16-byte aligned.
+#pragma once
+#include "stencil_kernels.hpp"
+
+namespace pde_amd {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int pad4(int h) { return (h + 3) / 4 * 4; }
+
+template <bool PER>
+__device__ __forceinline__ int wrap_quad(int c, int N, bool& ok) {
+  if (PER) {
+    if (c < 0) c += N;
+    else if (c >= N) c -= N;
+    c = min(max(c, 0), N - 4);
+  } else {
+    if (c < 0 || c >= N) { ok = false; c = 0; }
+  }
+  return c;
+}
+
+// Per-thread float4 elements of one halo tile; offsets are computed once per workgroup.
+template <class TL, bool P0, bool P1, bool P2, int NT>
+struct StagerQ {
+  static_assert(TL::D2 % 4 == 0 && TL::H2 % 4 == 0, "quad tiles need x extents in multiples of 4");
+  static constexpr int QROW = TL::D2 / 4;
+  static constexpr int NQ = TL::D0 * TL::D1 * QROW;
+  static constexpr int EPT = (NQ + NT - 1) / NT;
+  int off[EPT];
+  __device__ __forceinline__ void init(int o0, int o1, int o2, const Geom& g) {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = threadIdx.x + j * NT;
+      const int lq = i % QROW, rr = i / QROW, l1 = rr % TL::D1, l0 = rr / TL::D1;
+      bool ok = i < NQ;
+      const int c0 = wrap_coord<P0>(o0 + l0 - TL::H0, g.N0, ok);
+      const int c1 = wrap_coord<P1>(o1 + l1 - TL::H1, g.N1, ok);
+      const int c2 = wrap_quad<P2>(o2 + 4 * lq - TL::H2, g.N2, ok);
+      off[j] = ok ? (c0 * g.N1 + c1) * g.N2 + c2 : -1;
+    }
+  }
+  __device__ __forceinline__ void fetch(f4 (&v)[EPT], const float* __restrict__ frame) const {
+#pragma unroll
+    // always a valid address, and no use of the result here: the loads stay in flight until store()
+    for (int j = 0; j < EPT; ++j) v[j] = *reinterpret_cast<const f4*>(frame + max(off[j], 0));
+  }
+  __device__ __forceinline__ void store(const f4 (&v)[EPT], float* __restrict__ tile) const {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int i = threadIdx.x + j * NT;
+      const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (EPT * NT == NQ || i < NQ) *reinterpret_cast<f4*>(tile + 4 * i) = off[j] >= 0 ? v[j] : z;   // wall-side quads read 0
+    }
+  }
+};
+
+// Which quad of its row a lane owns.  With 16 quads per row a wave spans 4 rows whose LDS images are
+// S1 floats apart; ds_read_b128 is serviced in fixed 16-lane groups that mix lanes of two rows, and the
+// groups are conflict-free only if lane l sits in 16-byte slot (l mod 16).  Rotating the ownership by the
+// row skew restores that (the row still maps to one contiguous 256-byte segment of global memory).
+template <int QR, int S1>
+__device__ __forceinline__ int owned_quad() {
+  const int k = threadIdx.x % QR;
+  if (QR != 16) return k;
+  const int rw = (threadIdx.x % 64) / QR;
+  return (k + rw * (QR - S1 / 4)) & (QR - 1);
+}
+
+// element (px + o2) of the row, as "float4 number qd, lane e"
+#define PDE_AMD_QUAD_SPLIT(col, qd, e) \
+  const int qd = (col) >= 0 ? (col) / 4 : -((3 - (col)) / 4); \
+  const int e = (col) - 4 * qd;
+
+template <class P, class TL, class TX, int NS>
+struct RingAccQ : SiteBase<P> {
+  const float* fr[NS];       // &slot_of(tau - TLO + i)[field 0][row][quad start]
+  const float* ldsx;
+  int px;                    // which of the lane's 4 points
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const f4 v = *reinterpret_cast<const f4*>(fr[ot + P::TLO] + f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + 4 * qd);
+    return v[e];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const f4 v = *reinterpret_cast<const f4*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + 4 * qd);
+    return v[e];
+  }
+  __device__ __forceinline__ float G(int, int, int, int, int) const { return 0.0f; }
+};
+
+template <class P>
+struct QuadCfg {
+  // forward tile
+  using TL = Tile<P::QF0, P::QF1, P::QF2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), pad4(cmax(P::RH2, P::RT2))>;
+  using TXF = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, pad4(P::XH2)>;
+  static constexpr int NS = P::TLO + P::THI + 1;
+  static constexpr long FWD_BYTES = 4L * (NS * P::NF * TL::SIZE + (P::NA ? P::NA * TXF::SIZE : 0));
+  static constexpr bool FWD_OK = FWD_BYTES <= 64 * 1024 && P::QF2 % 4 == 0 && (P::QF0 * P::QF1 * (P::QF2 / 4)) % P::NTQ == 0 &&
+                                 P::NTQ % (P::QF2 / 4) == 0;
+  // backward tiles
+  // The region is evaluated on whole quads, so its outermost padding columns reach up to
+  // pad4(GH2) + RH2 - HB2 < 16 floats past a row end; those reads stay inside the LDS array (front and
+  // back pads of LDS_PAD floats) and only feed G columns that the gather never uses.
+  static constexpr int HB0 = cmax(P::GH0 + P::RH0, P::AH0), HB1 = cmax(P::GH1 + P::RH1, P::AH1),
+                       HB2 = pad4(cmax(P::GH2 + P::RH2, P::AH2));
+  static constexpr int LDS_PAD = 16;
+  static_assert(pad4(P::GH2) + P::RH2 - HB2 < LDS_PAD, "region overreach exceeds the LDS pad");
+  using TF = Tile<P::QB0, P::QB1, P::QB2, HB0, HB1, HB2>;
+  using TG = Tile<P::QB0, P::QB1, P::QB2, P::GH0, P::GH1, pad4(P::GH2)>;
+  using TXB = Tile<P::QB0, P::QB1, P::QB2, cmax(P::XH0, P::GH0), cmax(P::XH1, P::GH1), pad4(cmax(P::XH2, pad4(P::GH2)))>;
+  static constexpr long BWD_BYTES = 4L * (3 * P::NF * TF::SIZE + 2 * LDS_PAD + P::NE * TG::SIZE + (P::NA ? P::NA * TXB::SIZE : 0));
+  static constexpr bool BWD_OK = MarchOK<P>::value && BWD_BYTES <= LDS_BUDGET && P::QB2 % 4 == 0 &&
+                                 (P::QB0 * P::QB1 * (P::QB2 / 4)) % P::NTQ == 0 && P::NTQ % (P::QB2 / 4) == 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward, marching, quads: workgroup = (sample, chunk of residual frames, tile)
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::NTQ) void fwd_march_q_kernel(const Args a) {
+  using C = QuadCfg<P>;
+  using TL = typename C::TL;
+  using TX = typename C::TXF;
+  constexpr int NS = C::NS;
+  constexpr bool AUX_ON = P::NA > 0;
+  constexpr int NT = P::NTQ;
+  constexpr int QR = TL::T2 / 4;                        // quads per tile row
+  constexpr int QPT = (TL::T0 * TL::T1 * QR) / NT;      // quads (consecutive rows) per thread
+  using ST = StagerQ<TL, P::PER0, P::PER1, P::PER2, NT>;
+
+  __shared__ __attribute__((aligned(16))) float s_f[NS * P::NF * TL::SIZE];
+  __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
+  __shared__ double s_red[(NT / 64) * P::NE];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int nchunk = (g.TR + a.chunk - 1) / a.chunk;
+  const int tile = w % ntile, rest = w / ntile;
+  const int ch = rest % nchunk, b = rest / nchunk;
+  const int ra = P::TLO + ch * a.chunk;
+  const int rb = min(ra + a.chunk, g.T - P::THI);
+  const int o2 = (tile % g.nt2) * TL::T2, o1 = ((tile / g.nt2) % g.nt1) * TL::T1, o0 = (tile / (g.nt2 * g.nt1)) * TL::T0;
+
+  ST st;
+  st.init(o0, o1, o2, g);
+  const float* fb[P::NF];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
+
+  for (int fr = ra - P::TLO; fr <= ra + P::THI; ++fr) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) {
+      f4 v[ST::EPT];
+      st.fetch(v, fb[f] + (long)fr * g.S);
+      st.store(v, s_f + ((fr % NS) * P::NF + f) * TL::SIZE);
+    }
+  }
+  if (AUX_ON) {
+    using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT>;
+    SX sx;
+    sx.init(o0, o1, o2, g);
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x) {
+      f4 v[SX::EPT];
+      sx.fetch(v, a.aux[x] + (long)b * g.S);
+      sx.store(v, s_x + x * TX::SIZE);
+    }
+  }
+  __syncthreads();
+
+  RingAccQ<P, TL, TX, NS> acc;
+  acc.cc = a.c;
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = ldc(a.sp[i], b);
+  acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
+
+  int site[QPT], tsite[QPT], pi0[QPT], pi1[QPT], pi2[QPT];
+  bool rowok[QPT];
+#pragma unroll
+  for (int q = 0; q < QPT; ++q) {
+    const int row = (threadIdx.x / QR) * QPT + q;
+    const int l2 = 4 * owned_quad<QR, TL::S1>(), l1 = row % TL::T1, l0 = row / TL::T1;
+    pi0[q] = o0 + l0; pi1[q] = o1 + l1; pi2[q] = o2 + l2;
+    site[q] = TL::at(l0, l1, l2);
+    tsite[q] = TX::at(l0, l1, l2);
+    rowok[q] = pi0[q] < g.N0 && pi1[q] < g.N1 && pi0[q] >= g.lo0 && pi0[q] < g.N0 - g.hi0 && pi1[q] >= g.lo1 && pi1[q] < g.N1 - g.hi1;
+  }
+
+  double sum[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) sum[k] = 0.0;
+
+  float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + (ra - P::TLO));
+
+  for (int tau = ra; tau < rb; ++tau) {
+    const bool more = tau + 1 < rb;
+    const int fnew = tau + P::THI + 1;
+    f4 stage[P::NF][ST::EPT];
+    if (more) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
+    }
+    float wk[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) {
+      wk[k] = wnext[k];
+      wnext[k] = ldc(a.wt, k * g.TR + min(tau + 1 - P::TLO, g.TR - 1));
+    }
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      acc.i0 = pi0[q]; acc.i1 = pi1[q];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) acc.fr[i] = s_f + (((tau - P::TLO + i) % NS) * P::NF) * TL::SIZE + site[q];
+      acc.ldsx = s_x + tsite[q];
+      float part[P::NE];
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) part[k] = 0.0f;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        acc.px = px; acc.i2 = pi2[q] + px;
+        float R[P::NE];
+        P::residual(acc, R);
+        const bool ok = rowok[q] && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) {
+          const float r = ok ? R[k] : 0.0f;
+          part[k] += r * r;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) sum[k] += (double)part[k] * (double)wk[k];
+    }
+    if (more) {
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % NS) * P::NF + f) * TL::SIZE);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  block_sum_store<P::NE, NT>(sum, s_red, a.partial + (long)w * P::NE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, marching with recomputation, quads (see bwd_march_kernel for the schedule)
+// ------------------------------------------------------------------------------------------------
+template <class P, class TF, class TG, class TX>
+struct MarchAdjAccQ : SiteBase<P> {
+  const float* ldsg;
+  const float* ldsf;
+  const float* ldsx;
+  float gm[MAXE], gp[MAXE];
+  int px;
+  __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
+    if (ot != 0) return ot < 0 ? gm[k] : gp[k];
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const f4 v = *reinterpret_cast<const f4*>(ldsg + k * TG::SIZE + o0 * TG::S0 + o1 * TG::S1 + 4 * qd);
+    return v[e];
+  }
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const f4 v = *reinterpret_cast<const f4*>(ldsf + f * TF::SIZE + o0 * TF::S0 + o1 * TF::S1 + 4 * qd);
+    return v[e];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const f4 v = *reinterpret_cast<const f4*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + 4 * qd);
+    return v[e];
+  }
+};
+
+// Diagnostic build only (-DPDE_AMD_STAMPS): per-phase shader-clock stamps of the first workgroups go to the
+// workspace pointer, which no other code of the kernel reads.  Never defined in the shipped library.
+#ifdef PDE_AMD_STAMPS
+#define PDE_AMD_STAMP(slot) \
+  do { if (a.partial && blockIdx.x < 16 && (threadIdx.x & 63) == 0 && (n - n0) < 20) { \
+    __builtin_amdgcn_sched_barrier(0); \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0); \
+    reinterpret_cast<unsigned long long*>(a.partial)[(((blockIdx.x * 4 + (threadIdx.x >> 6)) * 20) + (n - n0)) * 8 + (slot)] = t_; } } while (0)
+#else
+#define PDE_AMD_STAMP(slot) do {} while (0)
+#endif
+
+template <class P>
+__global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args a) {
+  using C = QuadCfg<P>;
+  using TF = typename C::TF;
+  using TG = typename C::TG;
+  using TX = typename C::TXB;
+  constexpr bool AUX_ON = P::NA > 0;
+  constexpr int NT = P::NTQ;
+  constexpr int QR = TG::T2 / 4;                         // quads per tile row
+  constexpr int QPT = (TG::T0 * TG::T1 * QR) / NT;       // output quads per thread
+  constexpr int GQR = TG::D2 / 4;                        // quads per region row
+  constexpr int NRQ = TG::D0 * TG::D1 * GQR;             // region quads
+  constexpr int RPT = (NRQ + NT - 1) / NT;
+  using ST = StagerQ<TF, P::PER0, P::PER1, P::PER2, NT>;
+  static_assert(C::BWD_OK, "PDE not eligible for the quad marching adjoint");
+
+  __shared__ __attribute__((aligned(16))) float s_fpad[3 * P::NF * TF::SIZE + 2 * C::LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float s_g[P::NE * TG::SIZE];
+  float* const s_f = s_fpad + C::LDS_PAD;
+  __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int nchunk = (g.T + a.chunk - 1) / a.chunk;
+  const int tile = w % ntile, rest = w / ntile;
+  const int ch = rest % nchunk, b = rest / nchunk;
+  const int qa = ch * a.chunk, qb = min(qa + a.chunk, g.T);
+  const int o2 = (tile % g.nt2) * TG::T2, o1 = ((tile / g.nt2) % g.nt1) * TG::T1, o0 = (tile / (g.nt2 * g.nt1)) * TG::T0;
+
+  ST st;
+  st.init(o0, o1, o2, g);
+  const float* fb[P::NF];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
+  float up[P::NE];
+  upstream_of<P>(a, b, up);
+
+  const int na = max(qa - 1, 1), nb = min(qb, g.T - 2);
+  const int n0 = qa - 1;
+  for (int fr = max(n0 - 1, 0); fr <= min(n0 + 1, g.T - 1); ++fr) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) {
+      f4 v[ST::EPT];
+      st.fetch(v, fb[f] + (long)fr * g.S);
+      st.store(v, s_f + ((fr % 3) * P::NF + f) * TF::SIZE);
+    }
+  }
+  if (AUX_ON) {
+    using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT>;
+    SX sx;
+    sx.init(o0, o1, o2, g);
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x) {
+      f4 v[SX::EPT];
+      sx.fetch(v, a.aux[x] + (long)b * g.S);
+      sx.store(v, s_x + x * TX::SIZE);
+    }
+  }
+
+  // region quads of this thread (tile plus the adjoint's reach, x reach rounded up to whole quads)
+  int rF[RPT], rG[RPT], rX[RPT], r0[RPT], r1[RPT], r2[RPT];
+  bool rrow[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int iraw = threadIdx.x + j * NT;
+    const int i = iraw < NRQ ? iraw : 0;
+    const int lq = i % GQR, rr = i / GQR;
+    const int l2 = 4 * lq - TG::H2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
+    bool ok = iraw < NRQ;
+    const int c0 = wrap_coord<P::PER0>(o0 + l0, g.N0, ok);
+    const int c1 = wrap_coord<P::PER1>(o1 + l1, g.N1, ok);
+    const int c2 = wrap_quad<P::PER2>(o2 + l2, g.N2, ok);
+    r0[j] = c0; r1[j] = c1; r2[j] = c2;
+    rrow[j] = ok && c0 >= g.lo0 && c0 < g.N0 - g.hi0 && c1 >= g.lo1 && c1 < g.N1 - g.hi1;
+    rG[j] = 4 * i;
+    rF[j] = TF::at(l0, l1, l2);
+    rX[j] = TX::at(l0, l1, l2);
+  }
+  int sF[QPT], sG[QPT], sX[QPT], goff[QPT], pi0[QPT], pi1[QPT], pi2[QPT];
+  bool inside[QPT];
+#pragma unroll
+  for (int q = 0; q < QPT; ++q) {
+    const int row = (threadIdx.x / QR) * QPT + q;
+    const int l2 = 4 * owned_quad<QR, TG::S1>(), l1 = row % TG::T1, l0 = row / TG::T1;
+    pi0[q] = o0 + l0; pi1[q] = o1 + l1; pi2[q] = o2 + l2;
+    inside[q] = pi0[q] < g.N0 && pi1[q] < g.N1 && pi2[q] < g.N2;
+    sF[q] = TF::at(l0, l1, l2); sG[q] = TG::at(l0, l1, l2); sX[q] = TX::at(l0, l1, l2);
+    goff[q] = (pi0[q] * g.N1 + pi1[q]) * g.N2 + pi2[q];
+  }
+
+  RingAccQ<P, TF, TX, 3> racc;
+  racc.cc = a.c;
+  MarchAdjAccQ<P, TF, TG, TX> aacc;
+  aacc.cc = a.c;
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) { racc.spv[i] = ldc(a.sp[i], b); aacc.spv[i] = racc.spv[i]; }
+  racc.N0 = aacc.N0 = g.N0; racc.N1 = aacc.N1 = g.N1; racc.N2 = aacc.N2 = g.N2;
+
+  float Sprev[QPT][4][P::NF];
+  float Gm2[QPT][4][P::NE];
+  float Gm1[QPT][4][P::NE];
+#pragma unroll
+  for (int q = 0; q < QPT; ++q)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) { Gm2[q][px][k] = 0.0f; Gm1[q][px][k] = 0.0f; }
+    }
+  __syncthreads();
+
+  float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + min(max(n0 - 1, 0), g.TR - 1));
+
+  for (int n = n0; n <= qb; ++n) {
+    const int fnew = n + 2;
+    const bool more = n < qb && fnew < g.T;
+    PDE_AMD_STAMP(0);
+    f4 stage[P::NF][ST::EPT];
+    if (more) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
+    }
+    PDE_AMD_STAMP(1);
+
+    // G(n) = coef * R(n) on the tile plus the adjoint's reach
+    const bool gvalid = n >= na && n <= nb;
+    float cf[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) {
+      cf[k] = gvalid ? up[k] * wnext[k] : 0.0f;
+      wnext[k] = ldc(a.wt, k * g.TR + min(max(n, 0), g.TR - 1));
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      if (RPT * NT == NRQ || j < RPT - 1 || threadIdx.x + j * NT < NRQ) {   // whole waves drop out of the last round
+        f4 Gq[P::NE];
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) Gq[k] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef PDE_AMD_ABL_NO_G
+        if (gvalid)
+#else
+        if (gvalid && a.chunk < 0)
+#endif
+        {
+          racc.i0 = r0[j]; racc.i1 = r1[j];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) racc.fr[i] = s_f + (((n + 2 + i) % 3) * P::NF) * TF::SIZE + rF[j];
+          racc.ldsx = s_x + rX[j];
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            racc.px = px; racc.i2 = r2[j] + px;
+            float R[P::NE];
+            P::residual(racc, R);
+            const bool ok = rrow[j] && racc.i2 >= g.lo2 && racc.i2 < g.N2 - g.hi2;
+#pragma unroll
+            for (int k = 0; k < P::NE; ++k) Gq[k][px] = ok ? cf[k] * R[k] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) *reinterpret_cast<f4*>(s_g + k * TG::SIZE + rG[j]) = Gq[k];
+      }
+    }
+    PDE_AMD_STAMP(2);
+    __syncthreads();
+    PDE_AMD_STAMP(3);
+
+    const bool do_space = n >= qa && n < qb;
+    const bool do_out = n - 1 >= qa && n - 1 < qb;
+    f4 out[QPT][P::NF];      // gradient of frame n-1; stored at the end of the step (see below)
+    const float* fcur = s_f + (((n + 3) % 3) * P::NF) * TF::SIZE;
+    const float* fprev = s_f + (((n + 2) % 3) * P::NF) * TF::SIZE;
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      aacc.i0 = pi0[q]; aacc.i1 = pi1[q];
+      aacc.ldsg = s_g + sG[q]; aacc.ldsx = s_x + sX[q];
+      f4 Gc[P::NE];
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) Gc[k] = *reinterpret_cast<const f4*>(s_g + k * TG::SIZE + sG[q]);
+      if (do_out) {
+        aacc.ldsf = fprev + sF[q];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          aacc.px = px; aacc.i2 = pi2[q] + px;
+#pragma unroll
+          for (int k = 0; k < P::NE; ++k) { aacc.gm[k] = Gm2[q][px][k]; aacc.gp[k] = Gc[k][px]; }
+          float gt[P::NF];
+          P::adjoint_time(aacc, gt);
+#pragma unroll
+          for (int f = 0; f < P::NF; ++f) out[q][f][px] = Sprev[q][px][f] + gt[f];
+        }
+      }
+      // One branch around all four points: the points share most of their LDS quads, and the loads are
+      // only merged when the four evaluations sit in one basic block.
+      float gs[4][P::NF];
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) gs[px][f] = 0.0f;
+#ifndef PDE_AMD_ABL_NO_GATHER
+      if (do_space)
+#else
+      if (do_space && a.chunk < 0)
+#endif
+      {
+        aacc.ldsf = fcur + sF[q];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          aacc.px = px; aacc.i2 = pi2[q] + px;
+          P::adjoint_space(aacc, gs[px]);
+        }
+      }
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = gs[px][f];
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) { Gm2[q][px][k] = Gm1[q][px][k]; Gm1[q][px][k] = Gc[k][px]; }
+      }
+    }
+    PDE_AMD_STAMP(4);
+    __syncthreads();
+    PDE_AMD_STAMP(5);
+    if (more) {
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % 3) * P::NF + f) * TF::SIZE);
+    }
+    PDE_AMD_STAMP(6);
+    // The gradient stores go out last: the wait for the prefetched frame above then covers loads only, and
+    // the stores have the whole next step to drain before anything waits on the vector-memory counter again.
+    if (do_out) {
+#pragma unroll
+      for (int q = 0; q < QPT; ++q) {
+        if (inside[q]) {
+          const long o = (long)b * g.T * g.S + (long)(n - 1) * g.S + goff[q];
+#pragma unroll
+          for (int f = 0; f < P::NF; ++f) *reinterpret_cast<f4*>(a.g[f] + o) = out[q][f];
+        }
+      }
+    }
+    if (more) __syncthreads();
+    PDE_AMD_STAMP(7);
+  }
+}
+
+}  // namespace pde_amd

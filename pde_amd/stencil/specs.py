@@ -38,6 +38,11 @@ class Spec:
     threads: int = 256           # workgroup size of the per-frame kernels
     threads_march: int = 256     # workgroup size of the time-marching kernels
     waves_per_simd: int = 2      # occupancy the marching adjoint is compiled for (__launch_bounds__ 2nd argument)
+    # register-blocked ("quad") marching kernels: a lane owns 4 consecutive points of a row
+    quad_fwd: Tuple[int, int, int] = (1, 16, 64)
+    quad_bwd: Tuple[int, int, int] = (1, 16, 64)
+    threads_quad: int = 256
+    waves_per_simd_quad: int = 2
 
     # derived
     def analyse(self):
@@ -110,8 +115,9 @@ def _reg(s: Spec):
     return s
 
 
-T1D = dict(tile_fwd=(1, 1, 256), tile_bwd=(1, 1, 256), threads=256)
-T3D = dict(tile_fwd=(2, 4, 64), tile_bwd=(4, 8, 64), threads=256)
+T1D = dict(tile_fwd=(1, 1, 256), tile_bwd=(1, 1, 256), threads=256, quad_fwd=(1, 1, 256), quad_bwd=(1, 1, 256), threads_quad=64)
+T3D = dict(tile_fwd=(2, 4, 64), tile_bwd=(4, 8, 64), threads=256, quad_fwd=(2, 8, 64), quad_bwd=(2, 8, 64), threads_quad=256)
+T2D_WIDE = dict(tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64), quad_fwd=(1, 8, 64), quad_bwd=(1, 8, 64), threads_quad=128)   # 4-field PDEs
 
 
 # ---- 1-D periodic family -----------------------------------------------------------------------
@@ -266,7 +272,7 @@ def _shear_flow():
     ru = _ddt(b, u) + conv(u) + _d1c2(b, p, 1, "dx") - nu * lap(u) - dc * u * div
     rv = _ddt(b, v) + conv(v) + _d1c2(b, p, 2, "dy") - nu * lap(v) - dc * v * div
     rs = _ddt(b, s) + conv(s) - D * lap(s) - dc * s * div
-    return b.done([div, ru, rv, rs], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+    return b.done([div, ru, rv, rs], **T2D_WIDE)
 
 
 def _burgers2d_ch():
@@ -289,7 +295,7 @@ def _active_matter():
     dT, dc = b.c("d_T", _k("d_T")), b.c("div_corr", _k("div_corr"))
     rc = _ddt(b, c) + conv(c) - dT * lap(c) - dc * c * div
     rd = _ddt(b, dxx) + conv(dxx) - dT * lap(dxx) - dc * dxx * div
-    return b.done([div, rc, rd], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+    return b.done([div, rc, rd], **T2D_WIDE)
 
 
 # ---- 2-D mixed periodic / wall family ----------------------------------------------------------
@@ -326,7 +332,7 @@ def _turbulent_radiative():
     mass = _ddt(b, rho) + dx(rho * vx) + dy(rho * vy)
     xm = _ddt(b, rho * vx) + dx(rho * vx * vx + P) + dy(rho * vx * vy)
     ym = _ddt(b, rho * vy) + dx(rho * vx * vy) + dy(rho * vy * vy + P)
-    return b.done([mass, xm, ym], tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64))
+    return b.done([mass, xm, ym], **T2D_WIDE)
 
 
 def _wave_gauss():
