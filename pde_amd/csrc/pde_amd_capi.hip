@@ -3,6 +3,7 @@
 #include "stencil_kernels.hpp"
 #include "stencil_quad.hpp"
 #include <string.h>
+#include <stdlib.h>
 
 namespace pde_amd {
 #include "gen/registry.inc"
@@ -23,10 +24,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // The register-blocked kernels move 16 bytes per lane: every pointer must be 16-byte aligned and the
 // fastest extent a multiple of 4.
-template <int N>
-static inline bool aligned16(const float* const* p) {
+template <int N, int W>
+static inline bool aligned_vec(const float* const* p) {
   for (int i = 0; i < N; ++i)
-    if (reinterpret_cast<uintptr_t>(p[i]) & 15) return false;
+    if (reinterpret_cast<uintptr_t>(p[i]) & (4 * W - 1)) return false;
   return true;
 }
 static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -118,14 +119,15 @@ struct Ops {
       items = tr * tiles;
       if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
       hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
-    } else if (QuadCfg<P>::FWD_OK && p->n[2] % 4 == 0 && aligned16<P::NF>(fields) && (!P::NA || aligned16<P::NA>(aux))) {
-      if constexpr (QuadCfg<P>::FWD_OK) {
+    } else if (QuadCfg<P, P::QWF>::FWD_OK && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
+               (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
+      if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
         fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
         const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
         a.chunk = pick_chunk(p->batch * qtiles, (int)tr);
         items = cdiv((int)tr, a.chunk) * qtiles;
         if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
-        hipLaunchKernelGGL((fwd_march_q_kernel<P>), dim3((unsigned)(p->batch * items)), dim3(P::NTQ), 0, stream, a);
+        hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
       }
     } else if constexpr (FwdMarchFits<P>::value) {
       a.chunk = pick_chunk(p->batch * tiles, (int)tr);
@@ -179,15 +181,20 @@ struct Ops {
       const long nwg = (long)p->batch * p->frames * tiles;
       if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
       hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
-    } else if (QuadCfg<P>::BWD_OK && p->n[2] % 4 == 0 && aligned16<P::NF>(fields) && aligned16<P::NF>(grads) &&
-               (!P::NA || aligned16<P::NA>(aux))) {
-      if constexpr (QuadCfg<P>::BWD_OK) {
+    } else if (QuadCfg<P, P::QWB>::BWD_OK && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) &&
+               aligned_vec<P::NF, P::QWB>(grads) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
+      if constexpr (QuadCfg<P, P::QWB>::BWD_OK) {
         fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);
         const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
         a.chunk = pick_chunk(p->batch * qtiles, p->frames);
         const long nwg = (long)p->batch * cdiv(p->frames, a.chunk) * qtiles;
         if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
-        hipLaunchKernelGGL((bwd_march_q_kernel<P>), dim3((unsigned)nwg), dim3(P::NTQ), 0, stream, a);
+        #ifdef PDE_AMD_STAMPS
+        static const int dyn_lds = getenv("PDE_AMD_DYN_LDS") ? atoi(getenv("PDE_AMD_DYN_LDS")) : 0;   // diagnostic: caps workgroups per CU
+#else
+        constexpr int dyn_lds = 0;
+#endif
+        hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NT), dyn_lds, stream, a);
       }
     } else {
       if constexpr (BwdMarchFits<P>::value) {

@@ -1,43 +1,60 @@
 // Time-marching kernels, register-blocked along the fastest axis ("quad" kernels).
 //
-// A lane owns 4 consecutive points of a row.  Global loads and stores are 16 bytes per lane, LDS tiles
-// are read as aligned float4 (ds_read_b128: twice the bytes per LDS cycle of dword reads, a quarter of
-// the instructions), and the +-1..4 neighbours along the row come out of the lane's own registers.
+// A lane owns W = 4 or 2 consecutive points of a row (a "quad"; W is a template parameter).  Global loads
+// and stores are 4W bytes per lane, LDS tiles are read as aligned W-vectors (ds_read_b128 / ds_read_b64:
+// twice the bytes per LDS cycle of dword reads and 1/W of the instructions), and the neighbours along the
+// row come out of the lane's own registers.  W = 4 needs half the lanes of W = 2 for a tile but about twice
+// the registers per lane, so it runs at half the waves per SIMD: which one wins depends on the PDE.
 // The generated residual / adjoint code is unchanged: it is evaluated once per point with the point's
 // position inside the quad (`px`) known at compile time, so every stencil reference folds to
-// "element e of the float4 at compile-time offset d", and identical float4 loads are merged.
+// "element e of the vector at compile-time offset d", and identical vector loads are merged.
 //
 // Requirements (checked on the host, else the dword kernels of stencil_kernels.hpp run): the fastest
-// extent is a multiple of 4 and every field pointer is 16-byte aligned.
+// extent is a multiple of W and every field pointer is 4W-byte aligned.
 #pragma once
 #include "stencil_kernels.hpp"
 
 namespace pde_amd {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
+template <int W> struct VecOf;
+template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-constexpr int pad4(int h) { return (h + 3) / 4 * 4; }
+template <int W>
+__device__ __forceinline__ typename VecOf<W>::type vec_zero() {
+  typename VecOf<W>::type z;
+#pragma unroll
+  for (int i = 0; i < W; ++i) z[i] = 0.0f;
+  return z;
+}
 
-template <bool PER>
+// true in every lane iff the predicate holds in all active lanes of the wave (a scalar-register result)
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
+
+template <int W> constexpr int padw(int h) { return (h + W - 1) / W * W; }
+
+template <bool PER, int W>
 __device__ __forceinline__ int wrap_quad(int c, int N, bool& ok) {
   if (PER) {
     if (c < 0) c += N;
     else if (c >= N) c -= N;
-    c = min(max(c, 0), N - 4);
+    c = min(max(c, 0), N - W);
   } else {
     if (c < 0 || c >= N) { ok = false; c = 0; }
   }
   return c;
 }
 
-// Per-thread float4 elements of one halo tile; offsets are computed once per workgroup.
-template <class TL, bool P0, bool P1, bool P2, int NT>
+// Per-thread vector elements of one halo tile; offsets are computed once per workgroup.
+template <class TL, bool P0, bool P1, bool P2, int NT, int W>
 struct StagerQ {
-  static_assert(TL::D2 % 4 == 0 && TL::H2 % 4 == 0, "quad tiles need x extents in multiples of 4");
-  static constexpr int QROW = TL::D2 / 4;
+  using fv = typename VecOf<W>::type;
+  static_assert(TL::D2 % W == 0 && TL::H2 % W == 0, "quad tiles need x extents in multiples of the lane width");
+  static constexpr int QROW = TL::D2 / W;
   static constexpr int NQ = TL::D0 * TL::D1 * QROW;
   static constexpr int EPT = (NQ + NT - 1) / NT;
   int off[EPT];
+  bool plain[EPT];       // wave-uniform: no lane of the wave has to substitute zeros for element j
   __device__ __forceinline__ void init(int o0, int o1, int o2, const Geom& g) {
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -46,99 +63,120 @@ struct StagerQ {
       bool ok = i < NQ;
       const int c0 = wrap_coord<P0>(o0 + l0 - TL::H0, g.N0, ok);
       const int c1 = wrap_coord<P1>(o1 + l1 - TL::H1, g.N1, ok);
-      const int c2 = wrap_quad<P2>(o2 + 4 * lq - TL::H2, g.N2, ok);
+      const int c2 = wrap_quad<P2, W>(o2 + W * lq - TL::H2, g.N2, ok);
       off[j] = ok ? (c0 * g.N1 + c1) * g.N2 + c2 : -1;
+      plain[j] = wave_all(ok || i >= NQ);
     }
   }
-  __device__ __forceinline__ void fetch(f4 (&v)[EPT], const float* __restrict__ frame) const {
+  __device__ __forceinline__ void fetch(fv (&v)[EPT], const float* __restrict__ frame) const {
 #pragma unroll
     // always a valid address, and no use of the result here: the loads stay in flight until store()
-    for (int j = 0; j < EPT; ++j) v[j] = *reinterpret_cast<const f4*>(frame + max(off[j], 0));
+    for (int j = 0; j < EPT; ++j) v[j] = *reinterpret_cast<const fv*>(frame + max(off[j], 0));
   }
-  __device__ __forceinline__ void store(const f4 (&v)[EPT], float* __restrict__ tile) const {
+  // An unconditional use of the fetched registers.  The compiler places its wait for a load at the first
+  // use; when every use sits under a branch, the path around the branch leaves the load "pending" in the
+  // compiler's bookkeeping and the next iteration drains the whole memory queue before it may reuse the
+  // registers.  Call this on every path before the conditional store().
+  __device__ __forceinline__ void touch(const fv (&v)[EPT]) const {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) asm volatile("" ::"v"(v[j]));
+  }
+  __device__ __forceinline__ void store(const fv (&v)[EPT], float* __restrict__ tile) const {
+    touch(v);      // elements past the tile end are fetched but not stored
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       const int i = threadIdx.x + j * NT;
-      const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (EPT * NT == NQ || i < NQ) *reinterpret_cast<f4*>(tile + 4 * i) = off[j] >= 0 ? v[j] : z;   // wall-side quads read 0
+      const fv z = vec_zero<W>();
+      if (EPT * NT == NQ || i < NQ) {
+        // wall-side quads read 0; the select is skipped (a real branch) where no lane of the wave needs it
+        if (plain[j]) *reinterpret_cast<fv*>(tile + W * i) = v[j];
+        else *reinterpret_cast<fv*>(tile + W * i) = off[j] >= 0 ? v[j] : z;
+      }
     }
   }
 };
 
-// Which quad of its row a lane owns.  With 16 quads per row a wave spans 4 rows whose LDS images are
-// S1 floats apart; ds_read_b128 is serviced in fixed 16-lane groups that mix lanes of two rows, and the
+// Which quad of its row a lane owns.  With 16 float4 quads per row a wave spans 4 rows whose LDS images
+// are S1 floats apart; ds_read_b128 is serviced in fixed 16-lane groups that mix lanes of two rows, and the
 // groups are conflict-free only if lane l sits in 16-byte slot (l mod 16).  Rotating the ownership by the
 // row skew restores that (the row still maps to one contiguous 256-byte segment of global memory).
-template <int QR, int S1>
+// ds_read_b64 is serviced in 32-lane halves, which are whole rows when a row has 32 pairs: no rotation.
+template <int QR, int S1, int W>
 __device__ __forceinline__ int owned_quad() {
   const int k = threadIdx.x % QR;
-  if (QR != 16) return k;
+  if (W != 4 || QR != 16) return k;
   const int rw = (threadIdx.x % 64) / QR;
   return (k + rw * (QR - S1 / 4)) & (QR - 1);
 }
 
-// element (px + o2) of the row, as "float4 number qd, lane e"
+// element (px + o2) of the row, as "vector number qd, lane e"
 #define PDE_AMD_QUAD_SPLIT(col, qd, e) \
-  const int qd = (col) >= 0 ? (col) / 4 : -((3 - (col)) / 4); \
-  const int e = (col) - 4 * qd;
+  const int qd = (col) >= 0 ? (col) / W : -((W - 1 - (col)) / W); \
+  const int e = (col) - W * qd;
 
-template <class P, class TL, class TX, int NS>
+template <class P, class TL, class TX, int NS, int W>
 struct RingAccQ : SiteBase<P> {
+  using fv = typename VecOf<W>::type;
   const float* fr[NS];       // &slot_of(tau - TLO + i)[field 0][row][quad start]
   const float* ldsx;
   int px;                    // which of the lane's 4 points
   __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
-    const f4 v = *reinterpret_cast<const f4*>(fr[ot + P::TLO] + f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + 4 * qd);
+    const fv v = *reinterpret_cast<const fv*>(fr[ot + P::TLO] + f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + W * qd);
     return v[e];
   }
   __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
-    const f4 v = *reinterpret_cast<const f4*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + 4 * qd);
+    const fv v = *reinterpret_cast<const fv*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + W * qd);
     return v[e];
   }
   __device__ __forceinline__ float G(int, int, int, int, int) const { return 0.0f; }
 };
 
-template <class P>
+template <class P, int W>
 struct QuadCfg {
+  static_assert(W == 2 || W == 4, "lane width");
+  // the same tile is covered by 4/W times the lanes, each with about W/4 of the registers
+  static constexpr int NT = P::NTQ * 4 / W;
+  static constexpr int WPS = P::WPSQ * 4 / W;
   // forward tile
-  using TL = Tile<P::QF0, P::QF1, P::QF2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), pad4(cmax(P::RH2, P::RT2))>;
-  using TXF = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, pad4(P::XH2)>;
+  using TL = Tile<P::QF0, P::QF1, P::QF2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), padw<W>(cmax(P::RH2, P::RT2))>;
+  using TXF = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, padw<W>(P::XH2)>;
   static constexpr int NS = P::TLO + P::THI + 1;
   static constexpr long FWD_BYTES = 4L * (NS * P::NF * TL::SIZE + (P::NA ? P::NA * TXF::SIZE : 0));
-  static constexpr bool FWD_OK = FWD_BYTES <= 64 * 1024 && P::QF2 % 4 == 0 && (P::QF0 * P::QF1 * (P::QF2 / 4)) % P::NTQ == 0 &&
-                                 P::NTQ % (P::QF2 / 4) == 0;
+  static constexpr bool FWD_OK = FWD_BYTES <= 64 * 1024 && P::QF2 % W == 0 && (P::QF0 * P::QF1 * (P::QF2 / W)) % NT == 0 &&
+                                 NT % (P::QF2 / W) == 0 && NT <= 1024;
   // backward tiles
   // The region is evaluated on whole quads, so its outermost padding columns reach up to
-  // pad4(GH2) + RH2 - HB2 < 16 floats past a row end; those reads stay inside the LDS array (front and
+  // padw<W>(GH2) + RH2 - HB2 < 16 floats past a row end; those reads stay inside the LDS array (front and
   // back pads of LDS_PAD floats) and only feed G columns that the gather never uses.
   static constexpr int HB0 = cmax(P::GH0 + P::RH0, P::AH0), HB1 = cmax(P::GH1 + P::RH1, P::AH1),
-                       HB2 = pad4(cmax(P::GH2 + P::RH2, P::AH2));
+                       HB2 = padw<W>(cmax(P::GH2 + P::RH2, P::AH2));
   static constexpr int LDS_PAD = 16;
-  static_assert(pad4(P::GH2) + P::RH2 - HB2 < LDS_PAD, "region overreach exceeds the LDS pad");
+  static_assert(padw<W>(P::GH2) + P::RH2 - HB2 + W <= LDS_PAD, "region overreach exceeds the LDS pad");
   using TF = Tile<P::QB0, P::QB1, P::QB2, HB0, HB1, HB2>;
-  using TG = Tile<P::QB0, P::QB1, P::QB2, P::GH0, P::GH1, pad4(P::GH2)>;
-  using TXB = Tile<P::QB0, P::QB1, P::QB2, cmax(P::XH0, P::GH0), cmax(P::XH1, P::GH1), pad4(cmax(P::XH2, pad4(P::GH2)))>;
+  using TG = Tile<P::QB0, P::QB1, P::QB2, P::GH0, P::GH1, padw<W>(P::GH2)>;
+  using TXB = Tile<P::QB0, P::QB1, P::QB2, cmax(P::XH0, P::GH0), cmax(P::XH1, P::GH1), padw<W>(cmax(P::XH2, padw<W>(P::GH2)))>;
   static constexpr long BWD_BYTES = 4L * (3 * P::NF * TF::SIZE + 2 * LDS_PAD + P::NE * TG::SIZE + (P::NA ? P::NA * TXB::SIZE : 0));
-  static constexpr bool BWD_OK = MarchOK<P>::value && BWD_BYTES <= LDS_BUDGET && P::QB2 % 4 == 0 &&
-                                 (P::QB0 * P::QB1 * (P::QB2 / 4)) % P::NTQ == 0 && P::NTQ % (P::QB2 / 4) == 0;
+  static constexpr bool BWD_OK = MarchOK<P>::value && BWD_BYTES <= LDS_BUDGET && P::QB2 % W == 0 &&
+                                 (P::QB0 * P::QB1 * (P::QB2 / W)) % NT == 0 && NT % (P::QB2 / W) == 0 && NT <= 1024;
 };
 
 // ------------------------------------------------------------------------------------------------
 // forward, marching, quads: workgroup = (sample, chunk of residual frames, tile)
 // ------------------------------------------------------------------------------------------------
-template <class P>
-__global__ __launch_bounds__(P::NTQ) void fwd_march_q_kernel(const Args a) {
-  using C = QuadCfg<P>;
+template <class P, int W>
+__global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const Args a) {
+  using C = QuadCfg<P, W>;
+  using fv = typename VecOf<W>::type;
   using TL = typename C::TL;
   using TX = typename C::TXF;
   constexpr int NS = C::NS;
   constexpr bool AUX_ON = P::NA > 0;
-  constexpr int NT = P::NTQ;
-  constexpr int QR = TL::T2 / 4;                        // quads per tile row
+  constexpr int NT = C::NT;
+  constexpr int QR = TL::T2 / W;                        // quads per tile row
   constexpr int QPT = (TL::T0 * TL::T1 * QR) / NT;      // quads (consecutive rows) per thread
-  using ST = StagerQ<TL, P::PER0, P::PER1, P::PER2, NT>;
+  using ST = StagerQ<TL, P::PER0, P::PER1, P::PER2, NT, W>;
 
   __shared__ __attribute__((aligned(16))) float s_f[NS * P::NF * TL::SIZE];
   __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
@@ -163,40 +201,39 @@ __global__ __launch_bounds__(P::NTQ) void fwd_march_q_kernel(const Args a) {
   for (int fr = ra - P::TLO; fr <= ra + P::THI; ++fr) {
 #pragma unroll
     for (int f = 0; f < P::NF; ++f) {
-      f4 v[ST::EPT];
+      fv v[ST::EPT];
       st.fetch(v, fb[f] + (long)fr * g.S);
       st.store(v, s_f + ((fr % NS) * P::NF + f) * TL::SIZE);
     }
   }
   if (AUX_ON) {
-    using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT>;
+    using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT, W>;
     SX sx;
     sx.init(o0, o1, o2, g);
 #pragma unroll
     for (int x = 0; x < P::NA; ++x) {
-      f4 v[SX::EPT];
+      fv v[SX::EPT];
       sx.fetch(v, a.aux[x] + (long)b * g.S);
       sx.store(v, s_x + x * TX::SIZE);
     }
   }
   __syncthreads();
 
-  RingAccQ<P, TL, TX, NS> acc;
-  acc.cc = a.c;
-#pragma unroll
-  for (int i = 0; i < P::NSP; ++i) acc.spv[i] = ldc(a.sp[i], b);
+  RingAccQ<P, TL, TX, NS, W> acc;
+  acc.template set_uniforms<true>(a.c, a.sp, b);
   acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
 
   int site[QPT], tsite[QPT], pi0[QPT], pi1[QPT], pi2[QPT];
-  bool rowok[QPT];
+  bool rowok[QPT], wfull[QPT];      // wfull: wave-uniform, every point of every lane's quad lies on the lattice
 #pragma unroll
   for (int q = 0; q < QPT; ++q) {
     const int row = (threadIdx.x / QR) * QPT + q;
-    const int l2 = 4 * owned_quad<QR, TL::S1>(), l1 = row % TL::T1, l0 = row / TL::T1;
+    const int l2 = W * owned_quad<QR, TL::S1, W>(), l1 = row % TL::T1, l0 = row / TL::T1;
     pi0[q] = o0 + l0; pi1[q] = o1 + l1; pi2[q] = o2 + l2;
     site[q] = TL::at(l0, l1, l2);
     tsite[q] = TX::at(l0, l1, l2);
     rowok[q] = pi0[q] < g.N0 && pi1[q] < g.N1 && pi0[q] >= g.lo0 && pi0[q] < g.N0 - g.hi0 && pi1[q] >= g.lo1 && pi1[q] < g.N1 - g.hi1;
+    wfull[q] = wave_all(rowok[q] && pi2[q] >= g.lo2 && pi2[q] + W - 1 < g.N2 - g.hi2);
   }
 
   double sum[P::NE];
@@ -210,7 +247,7 @@ __global__ __launch_bounds__(P::NTQ) void fwd_march_q_kernel(const Args a) {
   for (int tau = ra; tau < rb; ++tau) {
     const bool more = tau + 1 < rb;
     const int fnew = tau + P::THI + 1;
-    f4 stage[P::NF][ST::EPT];
+    fv stage[P::NF][ST::EPT];
     if (more) {
 #pragma unroll
       for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
@@ -230,21 +267,30 @@ __global__ __launch_bounds__(P::NTQ) void fwd_march_q_kernel(const Args a) {
       float part[P::NE];
 #pragma unroll
       for (int k = 0; k < P::NE; ++k) part[k] = 0.0f;
+      float Rq[W][P::NE];
 #pragma unroll
-      for (int px = 0; px < 4; ++px) {
+      for (int px = 0; px < W; ++px) {
         acc.px = px; acc.i2 = pi2[q] + px;
-        float R[P::NE];
-        P::residual(acc, R);
-        const bool ok = rowok[q] && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
+        P::residual(acc, Rq[px]);
+      }
+      if (!wfull[q]) {      // off-lattice points contribute nothing
 #pragma unroll
-        for (int k = 0; k < P::NE; ++k) {
-          const float r = ok ? R[k] : 0.0f;
-          part[k] += r * r;
+        for (int px = 0; px < W; ++px) {
+          const int i2 = pi2[q] + px;
+          const bool ok = rowok[q] && i2 >= g.lo2 && i2 < g.N2 - g.hi2;
+#pragma unroll
+          for (int k = 0; k < P::NE; ++k) Rq[px][k] = ok ? Rq[px][k] : 0.0f;
         }
       }
 #pragma unroll
+      for (int px = 0; px < W; ++px)
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) part[k] += Rq[px][k] * Rq[px][k];
+#pragma unroll
       for (int k = 0; k < P::NE; ++k) sum[k] += (double)part[k] * (double)wk[k];
     }
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) st.touch(stage[f]);
     if (more) {
       __syncthreads();
 #pragma unroll
@@ -259,8 +305,9 @@ __global__ __launch_bounds__(P::NTQ) void fwd_march_q_kernel(const Args a) {
 // ------------------------------------------------------------------------------------------------
 // backward, marching with recomputation, quads (see bwd_march_kernel for the schedule)
 // ------------------------------------------------------------------------------------------------
-template <class P, class TF, class TG, class TX>
+template <class P, class TF, class TG, class TX, int W>
 struct MarchAdjAccQ : SiteBase<P> {
+  using fv = typename VecOf<W>::type;
   const float* ldsg;
   const float* ldsf;
   const float* ldsx;
@@ -269,17 +316,17 @@ struct MarchAdjAccQ : SiteBase<P> {
   __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
     if (ot != 0) return ot < 0 ? gm[k] : gp[k];
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
-    const f4 v = *reinterpret_cast<const f4*>(ldsg + k * TG::SIZE + o0 * TG::S0 + o1 * TG::S1 + 4 * qd);
+    const fv v = *reinterpret_cast<const fv*>(ldsg + k * TG::SIZE + o0 * TG::S0 + o1 * TG::S1 + W * qd);
     return v[e];
   }
   __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
-    const f4 v = *reinterpret_cast<const f4*>(ldsf + f * TF::SIZE + o0 * TF::S0 + o1 * TF::S1 + 4 * qd);
+    const fv v = *reinterpret_cast<const fv*>(ldsf + f * TF::SIZE + o0 * TF::S0 + o1 * TF::S1 + W * qd);
     return v[e];
   }
   __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
-    const f4 v = *reinterpret_cast<const f4*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + 4 * qd);
+    const fv v = *reinterpret_cast<const fv*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + W * qd);
     return v[e];
   }
 };
@@ -292,25 +339,26 @@ struct MarchAdjAccQ : SiteBase<P> {
     __builtin_amdgcn_sched_barrier(0); \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0); \
-    reinterpret_cast<unsigned long long*>(a.partial)[(((blockIdx.x * 4 + (threadIdx.x >> 6)) * 20) + (n - n0)) * 8 + (slot)] = t_; } } while (0)
+    reinterpret_cast<unsigned long long*>(a.partial)[(((blockIdx.x * 8 + (threadIdx.x >> 6)) * 20) + (n - n0)) * 8 + (slot)] = t_; } } while (0)
 #else
 #define PDE_AMD_STAMP(slot) do {} while (0)
 #endif
 
-template <class P>
-__global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args a) {
-  using C = QuadCfg<P>;
+template <class P, int W>
+__global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd_march_q_kernel(const Args a) {
+  using C = QuadCfg<P, W>;
+  using fv = typename VecOf<W>::type;
   using TF = typename C::TF;
   using TG = typename C::TG;
   using TX = typename C::TXB;
   constexpr bool AUX_ON = P::NA > 0;
-  constexpr int NT = P::NTQ;
-  constexpr int QR = TG::T2 / 4;                         // quads per tile row
+  constexpr int NT = C::NT;
+  constexpr int QR = TG::T2 / W;                         // quads per tile row
   constexpr int QPT = (TG::T0 * TG::T1 * QR) / NT;       // output quads per thread
-  constexpr int GQR = TG::D2 / 4;                        // quads per region row
+  constexpr int GQR = TG::D2 / W;                        // quads per region row
   constexpr int NRQ = TG::D0 * TG::D1 * GQR;             // region quads
   constexpr int RPT = (NRQ + NT - 1) / NT;
-  using ST = StagerQ<TF, P::PER0, P::PER1, P::PER2, NT>;
+  using ST = StagerQ<TF, P::PER0, P::PER1, P::PER2, NT, W>;
   static_assert(C::BWD_OK, "PDE not eligible for the quad marching adjoint");
 
   __shared__ __attribute__((aligned(16))) float s_fpad[3 * P::NF * TF::SIZE + 2 * C::LDS_PAD];
@@ -340,18 +388,18 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
   for (int fr = max(n0 - 1, 0); fr <= min(n0 + 1, g.T - 1); ++fr) {
 #pragma unroll
     for (int f = 0; f < P::NF; ++f) {
-      f4 v[ST::EPT];
+      fv v[ST::EPT];
       st.fetch(v, fb[f] + (long)fr * g.S);
       st.store(v, s_f + ((fr % 3) * P::NF + f) * TF::SIZE);
     }
   }
   if (AUX_ON) {
-    using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT>;
+    using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT, W>;
     SX sx;
     sx.init(o0, o1, o2, g);
 #pragma unroll
     for (int x = 0; x < P::NA; ++x) {
-      f4 v[SX::EPT];
+      fv v[SX::EPT];
       sx.fetch(v, a.aux[x] + (long)b * g.S);
       sx.store(v, s_x + x * TX::SIZE);
     }
@@ -359,20 +407,21 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
 
   // region quads of this thread (tile plus the adjoint's reach, x reach rounded up to whole quads)
   int rF[RPT], rG[RPT], rX[RPT], r0[RPT], r1[RPT], r2[RPT];
-  bool rrow[RPT];
+  bool rrow[RPT], rfull[RPT];      // rfull: wave-uniform, every point of every active lane's quad lies on the lattice
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int iraw = threadIdx.x + j * NT;
     const int i = iraw < NRQ ? iraw : 0;
     const int lq = i % GQR, rr = i / GQR;
-    const int l2 = 4 * lq - TG::H2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
+    const int l2 = W * lq - TG::H2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
     bool ok = iraw < NRQ;
     const int c0 = wrap_coord<P::PER0>(o0 + l0, g.N0, ok);
     const int c1 = wrap_coord<P::PER1>(o1 + l1, g.N1, ok);
-    const int c2 = wrap_quad<P::PER2>(o2 + l2, g.N2, ok);
+    const int c2 = wrap_quad<P::PER2, W>(o2 + l2, g.N2, ok);
     r0[j] = c0; r1[j] = c1; r2[j] = c2;
     rrow[j] = ok && c0 >= g.lo0 && c0 < g.N0 - g.hi0 && c1 >= g.lo1 && c1 < g.N1 - g.hi1;
-    rG[j] = 4 * i;
+    rfull[j] = wave_all(iraw >= NRQ || (rrow[j] && c2 >= g.lo2 && c2 + W - 1 < g.N2 - g.hi2));
+    rG[j] = W * i;
     rF[j] = TF::at(l0, l1, l2);
     rX[j] = TX::at(l0, l1, l2);
   }
@@ -381,28 +430,30 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
 #pragma unroll
   for (int q = 0; q < QPT; ++q) {
     const int row = (threadIdx.x / QR) * QPT + q;
-    const int l2 = 4 * owned_quad<QR, TG::S1>(), l1 = row % TG::T1, l0 = row / TG::T1;
+    const int l2 = W * owned_quad<QR, TG::S1, W>(), l1 = row % TG::T1, l0 = row / TG::T1;
     pi0[q] = o0 + l0; pi1[q] = o1 + l1; pi2[q] = o2 + l2;
     inside[q] = pi0[q] < g.N0 && pi1[q] < g.N1 && pi2[q] < g.N2;
     sF[q] = TF::at(l0, l1, l2); sG[q] = TG::at(l0, l1, l2); sX[q] = TX::at(l0, l1, l2);
     goff[q] = (pi0[q] * g.N1 + pi1[q]) * g.N2 + pi2[q];
   }
 
-  RingAccQ<P, TF, TX, 3> racc;
-  racc.cc = a.c;
-  MarchAdjAccQ<P, TF, TG, TX> aacc;
-  aacc.cc = a.c;
+  RingAccQ<P, TF, TX, 3, W> racc;
+  racc.template set_uniforms<true>(a.c, a.sp, b);
+  MarchAdjAccQ<P, TF, TG, TX, W> aacc;
+  aacc.vg = true;
 #pragma unroll
-  for (int i = 0; i < P::NSP; ++i) { racc.spv[i] = ldc(a.sp[i], b); aacc.spv[i] = racc.spv[i]; }
+  for (int i = 0; i < P::NC; ++i) aacc.cv[i] = racc.cv[i];
+#pragma unroll
+  for (int i = 0; i < P::NSP; ++i) aacc.spv[i] = racc.spv[i];
   racc.N0 = aacc.N0 = g.N0; racc.N1 = aacc.N1 = g.N1; racc.N2 = aacc.N2 = g.N2;
 
-  float Sprev[QPT][4][P::NF];
-  float Gm2[QPT][4][P::NE];
-  float Gm1[QPT][4][P::NE];
+  float Sprev[QPT][W][P::NF];
+  float Gm2[QPT][W][P::NE];
+  float Gm1[QPT][W][P::NE];
 #pragma unroll
   for (int q = 0; q < QPT; ++q)
 #pragma unroll
-    for (int px = 0; px < 4; ++px) {
+    for (int px = 0; px < W; ++px) {
 #pragma unroll
       for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = 0.0f;
 #pragma unroll
@@ -414,15 +465,26 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + min(max(n0 - 1, 0), g.TR - 1));
 
-  for (int n = n0; n <= qb; ++n) {
+  // Frames are fetched two steps before the step that needs them in LDS: the loads of frame n+3 are issued
+  // at the top of step n into one of two register sets and written to the ring at the end of step n+1, so a
+  // load has two steps of compute to hide behind.  The loop is unrolled by two so that both sets are
+  // statically named registers.
+  // The fetches are unconditional (past the end they re-read the last frame, an L2 hit, and the result is
+  // dropped): a fetch under a branch would make the compiler count, on the path around it, fewer loads in
+  // flight than there are, and its wait for the older set would then drain the younger set as well.
+#ifdef PDE_AMD_SKEW
+  if ((blockIdx.x / 256) & 1) { for (int i = 0; i < PDE_AMD_SKEW; ++i) __builtin_amdgcn_s_sleep(16); }
+#endif
+  fv stage_a[P::NF][ST::EPT], stage_b[P::NF][ST::EPT];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) st.fetch(stage_b[f], fb[f] + (long)min(n0 + 2, g.T - 1) * g.S);
+
+  auto step = [&](const int n, fv (&stage_new)[P::NF][ST::EPT], fv (&stage)[P::NF][ST::EPT]) __attribute__((always_inline)) {
     const int fnew = n + 2;
     const bool more = n < qb && fnew < g.T;
     PDE_AMD_STAMP(0);
-    f4 stage[P::NF][ST::EPT];
-    if (more) {
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
-    }
+    for (int f = 0; f < P::NF; ++f) st.fetch(stage_new[f], fb[f] + (long)min(n + 3, g.T - 1) * g.S);
     PDE_AMD_STAMP(1);
 
     // G(n) = coef * R(n) on the tile plus the adjoint's reach
@@ -430,15 +492,15 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
     float cf[P::NE];
 #pragma unroll
     for (int k = 0; k < P::NE; ++k) {
-      cf[k] = gvalid ? up[k] * wnext[k] : 0.0f;
+      cf[k] = to_vgpr(gvalid ? up[k] * wnext[k] : 0.0f);
       wnext[k] = ldc(a.wt, k * g.TR + min(max(n, 0), g.TR - 1));
     }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       if (RPT * NT == NRQ || j < RPT - 1 || threadIdx.x + j * NT < NRQ) {   // whole waves drop out of the last round
-        f4 Gq[P::NE];
+        fv Gq[P::NE];
 #pragma unroll
-        for (int k = 0; k < P::NE; ++k) Gq[k] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < P::NE; ++k) Gq[k] = vec_zero<W>();
 #ifndef PDE_AMD_ABL_NO_G
         if (gvalid)
 #else
@@ -450,17 +512,25 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
           for (int i = 0; i < 3; ++i) racc.fr[i] = s_f + (((n + 2 + i) % 3) * P::NF) * TF::SIZE + rF[j];
           racc.ldsx = s_x + rX[j];
 #pragma unroll
-          for (int px = 0; px < 4; ++px) {
+          for (int px = 0; px < W; ++px) {
             racc.px = px; racc.i2 = r2[j] + px;
             float R[P::NE];
             P::residual(racc, R);
-            const bool ok = rrow[j] && racc.i2 >= g.lo2 && racc.i2 < g.N2 - g.hi2;
 #pragma unroll
-            for (int k = 0; k < P::NE; ++k) Gq[k][px] = ok ? cf[k] * R[k] : 0.0f;
+            for (int k = 0; k < P::NE; ++k) Gq[k][px] = cf[k] * R[k];
+          }
+          if (!rfull[j]) {      // off-lattice points carry no residual
+#pragma unroll
+            for (int px = 0; px < W; ++px) {
+              const int i2 = r2[j] + px;
+              const bool ok = rrow[j] && i2 >= g.lo2 && i2 < g.N2 - g.hi2;
+#pragma unroll
+              for (int k = 0; k < P::NE; ++k) Gq[k][px] = ok ? Gq[k][px] : 0.0f;
+            }
           }
         }
 #pragma unroll
-        for (int k = 0; k < P::NE; ++k) *reinterpret_cast<f4*>(s_g + k * TG::SIZE + rG[j]) = Gq[k];
+        for (int k = 0; k < P::NE; ++k) *reinterpret_cast<fv*>(s_g + k * TG::SIZE + rG[j]) = Gq[k];
       }
     }
     PDE_AMD_STAMP(2);
@@ -469,20 +539,20 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
 
     const bool do_space = n >= qa && n < qb;
     const bool do_out = n - 1 >= qa && n - 1 < qb;
-    f4 out[QPT][P::NF];      // gradient of frame n-1; stored at the end of the step (see below)
+    fv out[QPT][P::NF];      // gradient of frame n-1; stored at the end of the step (see below)
     const float* fcur = s_f + (((n + 3) % 3) * P::NF) * TF::SIZE;
     const float* fprev = s_f + (((n + 2) % 3) * P::NF) * TF::SIZE;
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
       aacc.i0 = pi0[q]; aacc.i1 = pi1[q];
       aacc.ldsg = s_g + sG[q]; aacc.ldsx = s_x + sX[q];
-      f4 Gc[P::NE];
+      fv Gc[P::NE];
 #pragma unroll
-      for (int k = 0; k < P::NE; ++k) Gc[k] = *reinterpret_cast<const f4*>(s_g + k * TG::SIZE + sG[q]);
+      for (int k = 0; k < P::NE; ++k) Gc[k] = *reinterpret_cast<const fv*>(s_g + k * TG::SIZE + sG[q]);
       if (do_out) {
         aacc.ldsf = fprev + sF[q];
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
+        for (int px = 0; px < W; ++px) {
           aacc.px = px; aacc.i2 = pi2[q] + px;
 #pragma unroll
           for (int k = 0; k < P::NE; ++k) { aacc.gm[k] = Gm2[q][px][k]; aacc.gp[k] = Gc[k][px]; }
@@ -494,9 +564,9 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
       }
       // One branch around all four points: the points share most of their LDS quads, and the loads are
       // only merged when the four evaluations sit in one basic block.
-      float gs[4][P::NF];
+      float gs[W][P::NF];
 #pragma unroll
-      for (int px = 0; px < 4; ++px)
+      for (int px = 0; px < W; ++px)
 #pragma unroll
         for (int f = 0; f < P::NF; ++f) gs[px][f] = 0.0f;
 #ifndef PDE_AMD_ABL_NO_GATHER
@@ -507,13 +577,13 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
       {
         aacc.ldsf = fcur + sF[q];
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
+        for (int px = 0; px < W; ++px) {
           aacc.px = px; aacc.i2 = pi2[q] + px;
           P::adjoint_space(aacc, gs[px]);
         }
       }
 #pragma unroll
-      for (int px = 0; px < 4; ++px) {
+      for (int px = 0; px < W; ++px) {
 #pragma unroll
         for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = gs[px][f];
 #pragma unroll
@@ -521,8 +591,11 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
       }
     }
     PDE_AMD_STAMP(4);
-    __syncthreads();
+    // the slot of frame n-1 is overwritten next; only the other-frame adjoint terms may still be reading it
+    if (P::TIME_AF) __syncthreads();
     PDE_AMD_STAMP(5);
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) st.touch(stage[f]);
     if (more) {
 #pragma unroll
       for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % 3) * P::NF + f) * TF::SIZE);
@@ -536,12 +609,19 @@ __global__ __launch_bounds__(P::NTQ, P::WPSQ) void bwd_march_q_kernel(const Args
         if (inside[q]) {
           const long o = (long)b * g.T * g.S + (long)(n - 1) * g.S + goff[q];
 #pragma unroll
-          for (int f = 0; f < P::NF; ++f) *reinterpret_cast<f4*>(a.g[f] + o) = out[q][f];
+          for (int f = 0; f < P::NF; ++f) *reinterpret_cast<fv*>(a.g[f] + o) = out[q][f];
         }
       }
     }
     if (more) __syncthreads();
     PDE_AMD_STAMP(7);
+  };
+  // Both halves always run (a step past qb finds nothing to do: no residual frame, no output, no store).
+  // A branch around the second half would be a path on which, in the compiler's bookkeeping, the first
+  // half's loads are still in flight at the loop head, and it would drain the memory queue there.
+  for (int n = n0; n <= qb; n += 2) {
+    step(n, stage_a, stage_b);
+    step(n + 1, stage_b, stage_a);
   }
 }
 

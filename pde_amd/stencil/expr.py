@@ -437,7 +437,9 @@ class Emitter:
     def _atom(self, e: E) -> str:
         a = self.acc
         if isinstance(e, Num):
-            return _flt(e.v)
+            # 0, 0.5, 1, 2, 4 are encoded inside a VALU instruction; any other literal goes through the accessor,
+            # which may keep it in a vector register (a literal in a 3-operand instruction costs a scalar operand)
+            return _flt(e.v) if abs(e.v) in (0.0, 0.5, 1.0, 2.0, 4.0) else f"{a}.k({_flt(e.v)})"
         if isinstance(e, Par):
             return f"{a}.{'c' if e.kind == 'c' else 'sp'}({e.i})"
         if isinstance(e, Ref):

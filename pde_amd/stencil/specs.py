@@ -38,11 +38,15 @@ class Spec:
     threads: int = 256           # workgroup size of the per-frame kernels
     threads_march: int = 256     # workgroup size of the time-marching kernels
     waves_per_simd: int = 2      # occupancy the marching adjoint is compiled for (__launch_bounds__ 2nd argument)
-    # register-blocked ("quad") marching kernels: a lane owns 4 consecutive points of a row
+    # register-blocked ("quad") marching kernels: a lane owns quad_width_* consecutive points of a row.
+    # threads_quad / waves_per_simd_quad are quoted for width 4; width 2 covers the same tile with twice
+    # the lanes at twice the waves per SIMD.
     quad_fwd: Tuple[int, int, int] = (1, 16, 64)
     quad_bwd: Tuple[int, int, int] = (1, 16, 64)
     threads_quad: int = 256
     waves_per_simd_quad: int = 2
+    quad_width_fwd: int = 4
+    quad_width_bwd: int = 4
 
     # derived
     def analyse(self):
@@ -117,7 +121,7 @@ def _reg(s: Spec):
 
 T1D = dict(tile_fwd=(1, 1, 256), tile_bwd=(1, 1, 256), threads=256, quad_fwd=(1, 1, 256), quad_bwd=(1, 1, 256), threads_quad=64)
 T3D = dict(tile_fwd=(2, 4, 64), tile_bwd=(4, 8, 64), threads=256, quad_fwd=(2, 8, 64), quad_bwd=(2, 8, 64), threads_quad=256)
-T2D_WIDE = dict(tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64), quad_fwd=(1, 8, 64), quad_bwd=(1, 8, 64), threads_quad=128)   # 4-field PDEs
+T2D_WIDE = dict(tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64), quad_fwd=(1, 8, 64), quad_bwd=(1, 8, 64), threads_quad=128, quad_width_fwd=2, quad_width_bwd=2)   # 4-field PDEs
 
 
 # ---- 1-D periodic family -----------------------------------------------------------------------
@@ -284,7 +288,7 @@ def _burgers2d_ch():
     ru = _ddt(b, u) + conv(u) - u * div - nu * lap(u)
     rv = _ddt(b, v) + conv(v) - v * div - nu * lap(v)
     irr = _d1c4(b, v, 2, "dx") - _d1c4(b, u, 1, "dy")
-    return b.done([ru, rv, irr])
+    return b.done([ru, rv, irr], quad_width_bwd=2)
 
 
 def _active_matter():

@@ -20,7 +20,7 @@ cp = prob.c_struct(fields[0].shape)
 grads = [torch.empty_like(f) for f in fields]
 one = torch.ones((), device=dev)
 ups = _lib.ptr_array([None, None, None, one], 4)
-dbg = torch.zeros(16 * 4 * 20 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(16 * 8 * 20 * 8, dtype=torch.int64, device=dev)
 for it in range(3):
     dbg.zero_()
     st = L.pde_amd_residual_backward(C.byref(cp), _lib.ptr_array(fields, 3), _lib.ptr_array([], 0), _lib.ptr_array([nu], 1),
@@ -28,11 +28,13 @@ for it in range(3):
                                      C.c_void_p(dbg.data_ptr()), dbg.numel() * 8, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert st == 0, st
     torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(16, 4, 20, 8).astype(np.float64)
+d = dbg.cpu().numpy().reshape(16, 8, 20, 8).astype(np.float64)
 names = ["top->loads issued", "G stage", "barrier1", "gather", "barrier2", "stage LDS store (waits loads)", "grad stores + barrier3"]
 for blk in (0, 5):
-    for wv in (0, 3):
+    for wv in (0, 3, 7):
         x = d[blk, wv]
+        if x[:, 0].max() == 0:
+            continue
         steps = [i for i in range(20) if x[i, 0] > 0 and x[i, 7] > 0]
         dur = np.array([[x[i, j + 1] - x[i, j] for j in range(7)] for i in steps[2:-2]])
         tot = np.array([x[i, 7] - x[i, 0] for i in steps[2:-2]])
