@@ -75,6 +75,21 @@ def cpu_baseline(seconds=12.0):
             "sample": f"oracle TaylorGreen2D fwd+bwd fp32, B={bs} T={T} {H}x{W}, best of {n - 1} after warm-up"}
 
 
+def measured_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed hardware-counter passes (tools/profile_round.sh):
+    2 x FETCH_SIZE + WRITE_SIZE, each collected in its own rocprofv3 --pmc run.  None when no measurement is on file."""
+    path = os.path.join(ROOT, "pde_amd", "measured", "tg2d_traffic.json")
+    try:
+        with open(path) as fh:
+            data = json.load(fh)
+    except OSError:
+        return None
+    for name, rec in data.items():
+        if kernel_substr in name:
+            return rec["total_bytes"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,10 +168,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank},
-            "roofline": {"bound": "hbm", "kernel": "adjoint (backward) stencil kernel incl. launch gap, HIP events",
+            "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step, HIP events "
+                                                     "on the launch stream around it)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
-                         "median_ms": bwd_ms[len(bwd_ms) // 2], "fwd_median_ms": fwd_ms[len(fwd_ms) // 2]},
+                         "traffic": measured_traffic("bwd_march_q_kernel"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
+                         "median_ms": bwd_ms[len(bwd_ms) // 2], "fwd_median_ms": fwd_ms[len(fwd_ms) // 2],
+                         "fwd_algorithmic_bytes": 4 * e_in, "fwd_traffic": measured_traffic("fwd_march_q_kernel")},
             "loss": float(red["total"]),
         }
         if world == 1 and not args.no_cpu_baseline:
