@@ -90,6 +90,77 @@ int pde_amd_residual_backward(const pde_amd_problem* prob,
                               const float* const* resid_in, float* const* grads,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Channel-last evaluation metrics.
+ *
+ * One pass over pred and target, both [groups][rows][channels] contiguous fp32 (channels innermost; "groups" are
+ * whatever leading axes the caller wants separate results for: samples, samples x frames, or 1).  For every
+ * (group, channel) it returns PDE_AMD_NSTAT fp64 numbers:
+ *   [0] sum (p-g)^2   [1] sum g^2   [2] sum g   [3] sum p   [4] sum (p-g)^2 / (g^2 + rse_eps)   [5] max |p-g|
+ * from which the host forms, with the reference's own epsilons,
+ *   compute_vrmse            finetune/train_taylor_green_2d_lora_v3.py:204-232 (per-channel mse, variance of g, overall rmse)
+ *   evaluate() accumulators  eval/eval_nrmse.py:125-155 (per channel and per frame sums of (p-g)^2 and g^2)
+ *   nrmse_per_sample/_channel tools/eval_rollout.py:60-90
+ *   compute_mean_rse         eval/eval_autoregressive.py:197-219
+ *   metric_func              eval/metrics.py:189-226 (RMSE, nRMSE, MPP-nRMSE, conserved-sum error, max error; there the
+ *                            caller passes channels = nt * nc of the PDEBench layout [nb, nx.., nt, nc]).
+ * channels <= 1024. */
+#define PDE_AMD_NSTAT 6
+size_t pde_amd_pair_stats_workspace_bytes(int64_t groups, int64_t rows, int32_t channels);
+int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
+                       float rse_eps, double* stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Index-list "term" losses on a channel-last tensor [outer][d0][d1][d2][C] (unused leading spatial axes = 1).
+ *
+ * A term selects the Cartesian product of four index lists (axes d0, d1, d2 and the channel axis; the lists
+ * live in one device int32 array `indices`, list k of a term starting at idx_off[k] with n[k] entries) and
+ * evaluates at each selected element   v = sum_j coef[j] * x[index + shift[j] along `axis`],
+ * x = pred - target (use_target = 1) or pred (use_target = 0).  sums[t] = sum of v^2 over the term, fp64.
+ * The slices the reference concatenates are one term each, so elements shared by two slices count twice,
+ * as they do there:
+ *   compute_boundary_loss   1-D finetune/train_burgers_1d_lora_v3.py:111-139, 2-D strips
+ *                           finetune/train_taylor_green_2d_lora_v3.py:132-166, 2-D edges
+ *                           finetune/train_shear_flow_lora_v3.py:111-146, 3-D faces finetune/train_heat_3d_lora_v3.py:109-141
+ *                           (its z faces select rows of the y axis by the channel list), 3-D shells
+ *                           finetune/train_advection_3d_lora_v3.py:110-159
+ *   compute_noslip_loss     finetune/train_ns_incom_lora_v3.py:150-176
+ *   compute_patch_boundary_loss finetune/train_rayleigh_benard_lora_v3.py:114-135 (taps 1, -2, 1)
+ * Backward: grad += scales[t] * d(sums[t]) / d pred for every term; `grad` has the shape of pred and must
+ * hold the values to accumulate into (zeros for a fresh gradient).  scales is a device array [n_terms]. */
+#define PDE_AMD_MAX_TERMS 12
+typedef struct pde_amd_term {
+  int32_t n[4];
+  int32_t idx_off[4];
+  int32_t axis, n_taps;
+  int32_t shift[3];
+  float coef[3];
+  int32_t use_target;
+} pde_amd_term;
+size_t pde_amd_terms_workspace_bytes(int32_t n_terms);
+int pde_amd_terms_forward(const float* pred, const float* target, int64_t outer, const int32_t* dims /* host [4]: d0 d1 d2 C */,
+                          const pde_amd_term* terms /* host */, int32_t n_terms, const int32_t* indices, double* sums,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                           const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scales,
+                           float* grad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * compute_pde_loss glue (finetune/train_taylor_green_2d_lora_v3.py:169-201, train_rayleigh_benard_lora_v3.py:178-216,
+ * train_burgers_1d_lora_v3.py:142-172, train_heat_3d_lora_v3.py:144-172, train_fullft_physonly.py:172-223):
+ *   fields[f][b][0][s]     = input [b][0][s][channels[f]]
+ *   fields[f][b][1 + t][s] = output[b][t][s][channels[f]]
+ * with output [B][T_out][S][C], input [B][T_in][S][C], S the product of the spatial extents.  transpose = 1
+ * swaps the last two spatial axes (rows x cols -> cols x rows) in the fields, which is what the
+ * Rayleigh-Benard trainer's u.transpose(-1, -2) feeds its loss.  The scatter is the gradient of the gather
+ * w.r.t. output: every element of grad_output [B][T_out][S][C] is written, zeros outside the gathered channels. */
+int pde_amd_gather_fields(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
+                          const int32_t* channels /* host */, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                          float* const* fields /* host array of device pointers */, void* stream);
+int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int64_t T_out, int64_t S, int32_t C,
+                                const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                                float* grad_output, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

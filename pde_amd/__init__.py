@@ -12,4 +12,17 @@ from .losses import (  # noqa: F401
     burgers_pde_loss, burgers_pde_loss_upwind,
 )
 
+from .boundary import (  # noqa: F401
+    compute_boundary_loss, boundary_loss_1d, boundary_loss_2d_strips, boundary_loss_2d_edges, boundary_loss_3d_faces,
+    boundary_loss_3d_shells, compute_noslip_loss, compute_patch_boundary_loss,
+)
+from .metrics import (  # noqa: F401
+    compute_vrmse, nrmse_per_sample, nrmse_per_channel, compute_rse, compute_mean_rse, metric_func, NRMSEAccumulator,
+)
+from .glue import (  # noqa: F401
+    gather_fields, create_pde_loss, compute_pde_loss_generic, PDE_LOSS_REGISTRY, compute_pde_loss_taylor_green_2d,
+    compute_pde_loss_rayleigh_benard, compute_pde_loss_shear_flow, compute_pde_loss_burgers_1d, compute_pde_loss_gray_scott,
+    compute_pde_loss_burgers_3d, compute_pde_loss_heat_3d,
+)
+
 __version__ = "0.1.0"

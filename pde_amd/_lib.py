@@ -31,6 +31,13 @@ class PdeInfo(C.Structure):
                 ("name", C.c_char_p)]
 
 
+class Term(C.Structure):
+    _fields_ = [("n", C.c_int32 * 4), ("idx_off", C.c_int32 * 4), ("axis", C.c_int32), ("n_taps", C.c_int32),
+                ("shift", C.c_int32 * 3), ("coef", C.c_float * 3), ("use_target", C.c_int32)]
+
+
+NSTAT, MAX_TERMS = 6, 12
+
 _lib = None
 
 # every exported symbol with its signature; tests check that the library exports exactly these
@@ -47,6 +54,20 @@ SIGNATURES = {
                                             C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t,
                                             C.c_void_p]),
+    "pde_amd_pair_stats_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "pde_amd_pair_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pde_amd_terms_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "pde_amd_terms_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(Term), C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pde_amd_terms_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(Term), C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pde_amd_gather_fields": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                        C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.POINTER(C.c_void_p), C.c_void_p]),
+    "pde_amd_scatter_field_grads": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                              C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_void_p]),
 }
 
 

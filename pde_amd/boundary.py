@@ -1,0 +1,266 @@
+"""Boundary-strip, wall and patch-seam losses on the model's channel-last tensors.
+
+Each function mirrors one reference helper (same name where the reference has one name per trainer the
+variant is spelled out).  They all reduce to sums of squares over a handful of "terms" (Cartesian
+products of index lists, one per slice the reference concatenates), evaluated by ONE forward launch
+per term set and differentiated by one launch per term; the tiny sqrt / mean epilogue is ordinary
+torch on [n_terms] numbers, so autograd chains it.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from . import reductions as R
+
+CH_VX, CH_VY = 0, 1      # finetune/train_ns_incom_lora_v3.py:74-75
+
+
+def valid_channels(channel_mask: torch.Tensor) -> List[int]:
+    """`torch.where(mask > 0)[0]` of the first row (finetune/train_taylor_green_2d_lora_v3.py:141-144)."""
+    m = channel_mask if channel_mask.dim() == 1 else channel_mask[0]
+    return [int(i) for i in torch.where(m > 0)[0].tolist()]
+
+
+class TermSet:
+    """Host description of a set of terms plus the cached device copy of their index lists."""
+
+    _cache: Dict[tuple, "TermSet"] = {}
+
+    def __init__(self, dims: Sequence[int]):
+        self.dims = [int(d) for d in dims]          # d0, d1, d2, C
+        self.terms: List[_lib.Term] = []
+        self.groups: List[int] = []                  # which mean a term belongs to
+        self.pool: List[int] = []
+        self.elems: List[int] = []                   # selected elements per outer index
+        self._dev: Dict[torch.device, torch.Tensor] = {}
+
+    def add(self, lists: Sequence[Sequence[int]], group: int = 0, use_target: bool = True, axis: int = 0,
+            taps: Sequence[Tuple[int, float]] = ((0, 1.0),)):
+        t = _lib.Term()
+        n = 1
+        for k in range(4):
+            t.n[k] = len(lists[k])
+            t.idx_off[k] = len(self.pool)
+            self.pool.extend(int(i) for i in lists[k])
+            n *= len(lists[k])
+        t.axis, t.n_taps = axis, len(taps)
+        for j, (s, c) in enumerate(taps):
+            t.shift[j], t.coef[j] = int(s), float(c)
+        t.use_target = int(use_target)
+        self.terms.append(t)
+        self.groups.append(group)
+        self.elems.append(n)
+
+    def indices(self, device) -> torch.Tensor:
+        if device not in self._dev:
+            self._dev[device] = torch.tensor(self.pool if self.pool else [0], dtype=torch.int32, device=device)
+        return self._dev[device]
+
+
+class _TermSums(torch.autograd.Function):
+    """sums[t] = sum of squared term values, fp64 [n_terms]; differentiable w.r.t. pred."""
+
+    @staticmethod
+    def forward(ctx, pred, target, ts: TermSet, outer: int):
+        be = R.get_backend()
+        ctx.ts, ctx.outer = ts, outer
+        ctx.save_for_backward(pred, target if target is not None else pred.new_empty(0))
+        ctx.has_target = target is not None
+        return be.terms_forward(pred, target, outer, ts.dims, ts.terms, ts.indices(pred.device))
+
+    @staticmethod
+    def backward(ctx, gsums):
+        pred, target = ctx.saved_tensors
+        be = R.get_backend()
+        grad = torch.zeros_like(pred)
+        be.terms_backward(pred, target if ctx.has_target else None, ctx.outer, ctx.ts.dims, ctx.ts.terms,
+                          ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous(), grad)
+        return grad, None, None, None
+
+
+def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous()
+
+
+def _term_means(pred, target, ts: TermSet, n_groups: int) -> List[torch.Tensor]:
+    """mean of the squared term values of each group, as fp64 0-dim tensors (nan for an empty group, like torch.mean)."""
+    pred = _prep(pred, "pred")
+    target = _prep(target, "target") if target is not None else None
+    outer = int(pred.shape[0]) * int(pred.shape[1])
+    sums = _TermSums.apply(pred, target, ts, outer)
+    out = []
+    for g in range(n_groups):
+        sel = [i for i, gg in enumerate(ts.groups) if gg == g]
+        cnt = outer * sum(ts.elems[i] for i in sel)
+        tot = sums[sel].sum()
+        out.append(tot / cnt if cnt > 0 else tot * float("nan"))
+    return out
+
+
+def _sl(n: int, s: slice) -> List[int]:
+    return list(range(n))[s]
+
+
+def _dims4(shape: Sequence[int], nd: int) -> List[int]:
+    """[d0, d1, d2, C] of a [B, T, *spatial(nd), C] tensor (leading spatial axes padded with 1)."""
+    sp = [int(v) for v in shape[2:2 + nd]]
+    return [1] * (3 - nd) + sp + [int(shape[-1])]
+
+
+def _cached(key, build) -> TermSet:
+    ts = TermSet._cache.get(key)
+    if ts is None:
+        if len(TermSet._cache) > 64:
+            TermSet._cache.clear()
+        ts = build()
+        TermSet._cache[key] = ts
+    return ts
+
+
+def _rmse(pred, target, ts) -> torch.Tensor:
+    mse = _term_means(pred, target, ts, 1)[0]
+    return torch.sqrt(mse + 1e-8).to(torch.float32)
+
+
+def boundary_loss_1d(pred, target, channel_mask, bc_width: int = 1) -> torch.Tensor:
+    """finetune/train_burgers_1d_lora_v3.py:111-139 — [B, T, X, C]; left and right strips of width bc_width."""
+    ch, w = valid_channels(channel_mask), bc_width
+    X = pred.shape[2]
+
+    def build():
+        ts = TermSet(_dims4(pred.shape, 1))
+        ts.add([[0], [0], _sl(X, slice(None, w)), ch])
+        ts.add([[0], [0], _sl(X, slice(-w, None)), ch])
+        return ts
+    return _rmse(pred, target, _cached(("1d", tuple(pred.shape[2:]), tuple(ch), w), build))
+
+
+def boundary_loss_2d_strips(pred, target, channel_mask, bc_width: int = 1) -> torch.Tensor:
+    """finetune/train_taylor_green_2d_lora_v3.py:132-166 (same in train_rayleigh_benard_lora_v3.py:138-175,
+    train_burgers_3d_apebench_lora.py:115-150) — [B, T, H, W, C]; top/bottom full rows, left/right without corners."""
+    ch, w = valid_channels(channel_mask), bc_width
+    H, W = pred.shape[2], pred.shape[3]
+
+    def build():
+        ts = TermSet(_dims4(pred.shape, 2))
+        allw = list(range(W))
+        ts.add([[0], _sl(H, slice(None, w)), allw, ch])
+        ts.add([[0], _sl(H, slice(-w, None)), allw, ch])
+        mid = _sl(H, slice(w, -w))
+        ts.add([[0], mid, _sl(W, slice(None, w)), ch])
+        ts.add([[0], mid, _sl(W, slice(-w, None)), ch])
+        return ts
+    return _rmse(pred, target, _cached(("2ds", tuple(pred.shape[2:]), tuple(ch), w), build))
+
+
+def boundary_loss_2d_edges(pred, target, channel_mask) -> torch.Tensor:
+    """finetune/train_shear_flow_lora_v3.py:111-146 — single-pixel edges; the four corners count twice."""
+    ch = valid_channels(channel_mask)
+    H, W = pred.shape[2], pred.shape[3]
+
+    def build():
+        ts = TermSet(_dims4(pred.shape, 2))
+        allh, allw = list(range(H)), list(range(W))
+        ts.add([[0], allh, [0], ch])
+        ts.add([[0], allh, [W - 1], ch])
+        ts.add([[0], [0], allw, ch])
+        ts.add([[0], [H - 1], allw, ch])
+        return ts
+    return _rmse(pred, target, _cached(("2de", tuple(pred.shape[2:]), tuple(ch)), build))
+
+
+def boundary_loss_3d_faces(pred, target, channel_mask) -> torch.Tensor:
+    """finetune/train_heat_3d_lora_v3.py:109-141 — [B, T, X, Y, Z, C]; six single-cell faces.  As in the reference,
+    the two z faces index the Y axis with the channel list and keep all C channels (:133-134), so Y must exceed
+    the largest valid channel index."""
+    ch = valid_channels(channel_mask)
+    X, Y, Z, Cn = pred.shape[2], pred.shape[3], pred.shape[4], pred.shape[5]
+    if ch and max(ch) >= Y:
+        raise IndexError(f"index {max(ch)} is out of bounds for dimension 3 with size {Y}")
+
+    def build():
+        ts = TermSet(_dims4(pred.shape, 3))
+        ax, ay, az, ac = list(range(X)), list(range(Y)), list(range(Z)), list(range(Cn))
+        ts.add([[0], ay, az, ch]); ts.add([[X - 1], ay, az, ch])
+        ts.add([ax, [0], az, ch]); ts.add([ax, [Y - 1], az, ch])
+        ts.add([ax, ch, [0], ac]); ts.add([ax, ch, [Z - 1], ac])
+        return ts
+    return _rmse(pred, target, _cached(("3df", tuple(pred.shape[2:]), tuple(ch)), build))
+
+
+def boundary_loss_3d_shells(pred, target, channel_mask, bc_width: int = 1) -> torch.Tensor:
+    """finetune/train_advection_3d_lora_v3.py:110-159 — six face slabs of width bc_width without double counting."""
+    ch, w = valid_channels(channel_mask), bc_width
+    X, Y, Z = pred.shape[2], pred.shape[3], pred.shape[4]
+
+    def build():
+        ts = TermSet(_dims4(pred.shape, 3))
+        ay, az = list(range(Y)), list(range(Z))
+        mx, my = _sl(X, slice(w, -w)), _sl(Y, slice(w, -w))
+        ts.add([_sl(X, slice(None, w)), ay, az, ch]); ts.add([_sl(X, slice(-w, None)), ay, az, ch])
+        ts.add([mx, _sl(Y, slice(None, w)), az, ch]); ts.add([mx, _sl(Y, slice(-w, None)), az, ch])
+        ts.add([mx, my, _sl(Z, slice(None, w)), ch]); ts.add([mx, my, _sl(Z, slice(-w, None)), ch])
+        return ts
+    return _rmse(pred, target, _cached(("3ds", tuple(pred.shape[2:]), tuple(ch), w), build))
+
+
+def compute_boundary_loss(pred, target, channel_mask, bc_width: int = 1, variant: Optional[str] = None) -> torch.Tensor:
+    """The reference has one `compute_boundary_loss` per trainer; `variant` picks which
+    ('1d', 'strips', 'edges', 'faces', 'shells'); by default the tensor rank decides: 4 -> '1d', 5 -> 'strips', 6 -> 'shells'."""
+    if variant is None:
+        variant = {4: "1d", 5: "strips", 6: "shells"}.get(pred.dim())
+    if variant == "1d":
+        return boundary_loss_1d(pred, target, channel_mask, bc_width)
+    if variant == "strips":
+        return boundary_loss_2d_strips(pred, target, channel_mask, bc_width)
+    if variant == "edges":
+        return boundary_loss_2d_edges(pred, target, channel_mask)
+    if variant == "faces":
+        return boundary_loss_3d_faces(pred, target, channel_mask)
+    if variant == "shells":
+        return boundary_loss_3d_shells(pred, target, channel_mask, bc_width)
+    raise ValueError(f"compute_boundary_loss: unknown variant {variant!r} for a {pred.dim()}-d tensor")
+
+
+def compute_noslip_loss(output, ch_vx: int = CH_VX, ch_vy: int = CH_VY) -> torch.Tensor:
+    """finetune/train_ns_incom_lora_v3.py:150-176 — mean(u_wall^2) + mean(v_wall^2) over the four walls (corners twice)."""
+    H, W = output.shape[2], output.shape[3]
+
+    def build():
+        ts = TermSet(_dims4(output.shape, 2))
+        allh, allw = list(range(H)), list(range(W))
+        for g, c in enumerate((ch_vx, ch_vy)):
+            ts.add([[0], [0], allw, [c]], group=g, use_target=False)
+            ts.add([[0], [H - 1], allw, [c]], group=g, use_target=False)
+            ts.add([[0], allh, [0], [c]], group=g, use_target=False)
+            ts.add([[0], allh, [W - 1], [c]], group=g, use_target=False)
+        return ts
+    mu, mv = _term_means(output, None, _cached(("noslip", tuple(output.shape[2:]), ch_vx, ch_vy), build), 2)
+    return (mu + mv).to(torch.float32)
+
+
+def compute_patch_boundary_loss(output, channel_mask, patch_size: int = 16) -> torch.Tensor:
+    """finetune/train_rayleigh_benard_lora_v3.py:114-135 — mean squared curvature x[P-2] - 2 x[P-1] + x[P] across every
+    patch seam, along W and along H."""
+    ch, P = valid_channels(channel_mask), patch_size
+    H, W = output.shape[2], output.shape[3]
+
+    def seams(n):
+        a, b, c = _sl(n, slice(P - 2, -2, P)), _sl(n, slice(P - 1, -1, P)), _sl(n, slice(P, None, P))
+        if not (len(a) == len(b) == len(c)):
+            raise RuntimeError(f"The size of tensor a ({len(a)}) must match the size of tensor b ({len(b)}) at a patch seam axis of length {n}")
+        return a
+
+    def build():
+        ts = TermSet(_dims4(output.shape, 2))
+        taps = ((0, 1.0), (1, -2.0), (2, 1.0))
+        ts.add([[0], list(range(H)), seams(W), ch], group=0, use_target=False, axis=2, taps=taps)
+        ts.add([[0], seams(H), list(range(W)), ch], group=1, use_target=False, axis=1, taps=taps)
+        return ts
+    mh, mv = _term_means(output, None, _cached(("patch", tuple(output.shape[2:]), tuple(ch), P), build), 2)
+    return (mh + mv).to(torch.float32)

@@ -1,0 +1,387 @@
+// C ABI (include/pde_amd.h) of the channel-last reductions and index-list "term" losses:
+//   pair statistics over [groups][rows][channels] tensors (nRMSE / VRMSE / RSE / RMSE families),
+//   sums of squares over unions of index-list boxes with optional 3-tap combinations (boundary strips,
+//   wall, patch-seam losses) and their gradients, and the field gather / gradient scatter between the
+//   model's channel-last tensors and the per-field tensors of the residual losses.
+#include "../../include/pde_amd.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pde_amd {
+namespace {
+
+constexpr int NSTAT = PDE_AMD_NSTAT;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair statistics.  Thread t of a workgroup of NT = m * C threads always sees channel t % C: the flat
+// element index of a group advances by NT per step, so loads are contiguous dwords across the workgroup
+// and the six accumulators of a thread belong to one channel.  Accumulation is fp64 throughout.
+// ------------------------------------------------------------------------------------------------
+constexpr int PS_UNROLL = 4;
+
+__global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           long rows, int C, int rows_per_step, long steps_per_block,
+                                                           int blocks_per_group, float rse_eps, double* __restrict__ partial) {
+  extern __shared__ double s_acc[];          // [NSTAT][NT]
+  const int NT = blockDim.x;
+  const int g = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
+  const long n = rows * (long)C;             // elements of the group
+  const float* p = pred + (long)g * n;
+  const float* q = target + (long)g * n;
+  const long first = (long)blk * steps_per_block * NT + threadIdx.x;
+  const long last = min(n, (long)(blk + 1) * steps_per_block * NT);
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+  float amax = 0.0f;
+  long i = first;
+  for (; i + (long)(PS_UNROLL - 1) * NT < last; i += (long)PS_UNROLL * NT) {
+    float pv[PS_UNROLL], gv[PS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) { pv[u] = p[i + (long)u * NT]; gv[u] = q[i + (long)u * NT]; }
+#pragma unroll
+    for (int u = 0; u < PS_UNROLL; ++u) {
+      const float d = pv[u] - gv[u];
+      const float d2 = d * d, g2 = gv[u] * gv[u];
+      a0 += (double)d2; a1 += (double)g2; a2 += (double)gv[u]; a3 += (double)pv[u];
+      a4 += (double)(d2 / (g2 + rse_eps));
+      amax = fmaxf(amax, fabsf(d));
+    }
+  }
+  for (; i < last; i += NT) {
+    const float pvv = p[i], gvv = q[i];
+    const float d = pvv - gvv;
+    const float d2 = d * d, g2 = gvv * gvv;
+    a0 += (double)d2; a1 += (double)g2; a2 += (double)gvv; a3 += (double)pvv;
+    a4 += (double)(d2 / (g2 + rse_eps));
+    amax = fmaxf(amax, fabsf(d));
+  }
+  s_acc[0 * NT + threadIdx.x] = a0;
+  s_acc[1 * NT + threadIdx.x] = a1;
+  s_acc[2 * NT + threadIdx.x] = a2;
+  s_acc[3 * NT + threadIdx.x] = a3;
+  s_acc[4 * NT + threadIdx.x] = a4;
+  s_acc[5 * NT + threadIdx.x] = (double)amax;
+  __syncthreads();
+  // thread (s, c): fixed-order sum over the threads of channel c
+  for (int w = threadIdx.x; w < NSTAT * C; w += NT) {
+    const int s = w / C, c = w % C;
+    double r = 0.0;
+    if (s < 5) { for (int t = c; t < NT; t += C) r += s_acc[s * NT + t]; }
+    else { for (int t = c; t < NT; t += C) r = fmax(r, s_acc[s * NT + t]); }
+    partial[((long)blockIdx.x * C + c) * NSTAT + s] = r;
+  }
+  (void)rows_per_step;
+}
+
+__global__ void pair_stats_finalize_kernel(const double* __restrict__ partial, int blocks_per_group, int C, double* __restrict__ stats) {
+  const int g = blockIdx.x;
+  for (int w = threadIdx.x; w < NSTAT * C; w += blockDim.x) {
+    const int c = w / NSTAT, s = w % NSTAT;
+    double r = 0.0;
+    for (int b = 0; b < blocks_per_group; ++b) {
+      const double v = partial[(((long)g * blocks_per_group + b) * C + c) * NSTAT + s];
+      r = s < 5 ? r + v : fmax(r, v);
+    }
+    stats[((long)g * C + c) * NSTAT + s] = r;
+  }
+}
+
+struct PairPlan {
+  int nt, blocks_per_group;
+  long steps_per_block;
+};
+
+inline bool pair_plan(long groups, long rows, int C, PairPlan& pl) {
+  if (groups <= 0 || rows <= 0 || C <= 0 || C > 1024) return false;
+  int m = 768 / C;
+  if (m < 1) m = 1;
+  pl.nt = m * C;
+  const long n = rows * (long)C;
+  const long steps = (n + pl.nt - 1) / pl.nt;
+  // about 2048 workgroups in total, at least 8 steps each
+  long bpg = (2048 + groups - 1) / groups;
+  const long maxb = (steps + 7) / 8;
+  if (bpg > maxb) bpg = maxb;
+  if (bpg < 1) bpg = 1;
+  pl.steps_per_block = (steps + bpg - 1) / bpg;
+  pl.blocks_per_group = (int)((steps + pl.steps_per_block - 1) / pl.steps_per_block);
+  return groups * (long)pl.blocks_per_group < (1L << 31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// terms: tensor [outer][d0][d1][d2][C]; a term is the Cartesian product of four index lists, and the value at
+// a product element is sum_j coef_j * x[... + shift_j along `axis`], x = pred - target or pred alone.
+// ------------------------------------------------------------------------------------------------
+struct TermArgs {
+  const float* pred;
+  const float* target;
+  const int32_t* indices;
+  long outer;
+  long stride[4];       // element strides of d0, d1, d2, channel
+  long outer_stride;
+  pde_amd_term t;
+  long count;           // outer * n0 * n1 * n2 * nc
+};
+
+__device__ __forceinline__ float term_value(const TermArgs& a, long e, long& off, long& tap_stride) {
+  const pde_amd_term& t = a.t;
+  const int ic = (int)(e % t.n[3]); e /= t.n[3];
+  const int i2 = (int)(e % t.n[2]); e /= t.n[2];
+  const int i1 = (int)(e % t.n[1]); e /= t.n[1];
+  const int i0 = (int)(e % t.n[0]); e /= t.n[0];
+  off = e * a.outer_stride + a.indices[t.idx_off[0] + i0] * a.stride[0] + a.indices[t.idx_off[1] + i1] * a.stride[1] +
+        a.indices[t.idx_off[2] + i2] * a.stride[2] + a.indices[t.idx_off[3] + ic] * a.stride[3];
+  tap_stride = a.stride[t.axis];
+  float v = 0.0f;
+  for (int j = 0; j < t.n_taps; ++j) {
+    const long o = off + t.shift[j] * tap_stride;
+    const float x = t.use_target ? a.pred[o] - a.target[o] : a.pred[o];
+    v += t.coef[j] * x;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void term_fwd_kernel(const TermArgs a, double* __restrict__ partial) {
+  __shared__ double s_red[4];
+  double acc = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.count; e += (long)gridDim.x * 256) {
+    long off, ts;
+    const float v = term_value(a, e, off, ts);
+    acc += (double)(v * v);
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+struct BlockTable { int start[PDE_AMD_MAX_TERMS + 1]; };
+
+__global__ void term_finalize_kernel(const double* __restrict__ partial, const BlockTable blk, int n_terms, double* __restrict__ sums) {
+  const int t = threadIdx.x;
+  if (t < n_terms) {
+    double r = 0.0;
+    for (int b = blk.start[t]; b < blk.start[t + 1]; ++b) r += partial[b];
+    sums[t] = r;
+  }
+}
+
+// grad[...] += scale * 2 * value * coef_j at every tap; offsets inside one term never collide
+__global__ __launch_bounds__(256) void term_bwd_kernel(const TermArgs a, const float* __restrict__ scale_ptr, float* __restrict__ grad) {
+  const float scale = 2.0f * scale_ptr[0];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.count; e += (long)gridDim.x * 256) {
+    long off, ts;
+    const float v = term_value(a, e, off, ts);
+    for (int j = 0; j < a.t.n_taps; ++j) grad[off + a.t.shift[j] * ts] += scale * v * a.t.coef[j];
+  }
+}
+
+inline int term_blocks(long count) {
+  long b = (count + 1023) / 1024;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// field gather / gradient scatter between [B][T][S][C] model tensors and per-field [B][T+1][S] tensors
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+  const float* output;     // [B][T_out][S][C]
+  const float* input;      // [B][T_in][S][C], frame 0 is prepended
+  float* fields[PDE_AMD_MAX_FIELDS];
+  const float* gfields[PDE_AMD_MAX_FIELDS];
+  int32_t ch[PDE_AMD_MAX_FIELDS];
+  int nf, C;
+  long B, T_out, T_in, S;
+  int rows, cols, transpose;   // S = lead * rows * cols; transpose swaps the last two spatial axes in the fields
+};
+
+__device__ __forceinline__ long field_site(const GatherArgs& a, long s) {
+  if (!a.transpose) return s;
+  const long rc = (long)a.rows * a.cols;
+  const long lead = s / rc, r = (s % rc) / a.cols, c = s % a.cols;
+  return lead * rc + c * a.rows + r;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+  const long npts = a.B * (a.T_out + 1) * a.S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npts; i += (long)gridDim.x * 256) {
+    const long s = i % a.S, t = (i / a.S) % (a.T_out + 1), b = i / (a.S * (a.T_out + 1));
+    const float* src = t == 0 ? a.input + ((b * a.T_in) * a.S + s) * a.C : a.output + ((b * a.T_out + (t - 1)) * a.S + s) * a.C;
+    const long dst = (b * (a.T_out + 1) + t) * a.S + field_site(a, s);
+    for (int f = 0; f < a.nf; ++f) a.fields[f][dst] = src[a.ch[f]];
+  }
+}
+
+// one thread per float4 of grad_output; every element is written (zeros outside the gathered channels)
+__global__ __launch_bounds__(256) void scatter_kernel(const GatherArgs a, float* __restrict__ grad_output, long n_elems) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const long nvec = (n_elems + 3) / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long e = 4 * i + k;
+      float r = 0.0f;
+      if (e < n_elems) {
+        const int c = (int)(e % a.C);
+        const long pt = e / a.C;
+        for (int f = 0; f < a.nf; ++f) {
+          if (a.ch[f] == c) {
+            const long s = pt % a.S, t = (pt / a.S) % a.T_out, b = pt / (a.S * a.T_out);
+            r += a.gfields[f][(b * (a.T_out + 1) + t + 1) * a.S + field_site(a, s)];
+          }
+        }
+      }
+      v[k] = r;
+    }
+    if (4 * i + 3 < n_elems) *reinterpret_cast<f4*>(grad_output + 4 * i) = f4{v[0], v[1], v[2], v[3]};
+    else for (int k = 0; k < 4 && 4 * i + k < n_elems; ++k) grad_output[4 * i + k] = v[k];
+  }
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP; }
+
+}  // namespace
+}  // namespace pde_amd
+
+using namespace pde_amd;
+
+extern "C" {
+
+size_t pde_amd_pair_stats_workspace_bytes(int64_t groups, int64_t rows, int32_t channels) {
+  PairPlan pl;
+  if (!pair_plan(groups, rows, channels, pl)) return 0;
+  return (size_t)groups * pl.blocks_per_group * channels * NSTAT * sizeof(double);
+}
+
+int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
+                       float rse_eps, double* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  if (groups == 0 || rows == 0) {
+    if (groups < 0 || rows < 0 || channels <= 0) return PDE_AMD_EINVAL;
+    if (groups > 0 && stats) (void)hipMemsetAsync(stats, 0, (size_t)groups * channels * NSTAT * sizeof(double), (hipStream_t)stream);
+    return PDE_AMD_OK;
+  }
+  PairPlan pl;
+  if (!pair_plan(groups, rows, channels, pl)) return PDE_AMD_ESHAPE;
+  if (!pred || !target || !stats || !workspace) return PDE_AMD_EINVAL;
+  if (workspace_bytes < pde_amd_pair_stats_workspace_bytes(groups, rows, channels)) return PDE_AMD_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)workspace;
+  const size_t lds = (size_t)NSTAT * pl.nt * sizeof(double);
+  hipLaunchKernelGGL(pair_stats_kernel, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
+                     (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, partial);
+  hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)groups), dim3(128), 0, st, partial, pl.blocks_per_group, (int)channels, stats);
+  return check_launch();
+}
+
+static int fill_term_args(TermArgs& a, const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                          const pde_amd_term* t, const int32_t* indices) {
+  if (t->n_taps < 1 || t->n_taps > 3 || t->axis < 0 || t->axis > 2) return PDE_AMD_EINVAL;
+  if (t->use_target && !target) return PDE_AMD_EINVAL;
+  a.pred = pred; a.target = target; a.indices = indices; a.outer = outer;
+  a.stride[3] = 1; a.stride[2] = dims[3]; a.stride[1] = (long)dims[2] * dims[3]; a.stride[0] = (long)dims[1] * dims[2] * dims[3];
+  a.outer_stride = (long)dims[0] * dims[1] * dims[2] * dims[3];
+  a.t = *t;
+  a.count = outer;
+  for (int k = 0; k < 4; ++k) {
+    if (t->n[k] < 0) return PDE_AMD_EINVAL;
+    a.count *= t->n[k];
+  }
+  return PDE_AMD_OK;
+}
+
+size_t pde_amd_terms_workspace_bytes(int32_t n_terms) {
+  return n_terms <= 0 ? 0 : (size_t)n_terms * 1024 * sizeof(double);
+}
+
+int pde_amd_terms_forward(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                          const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, double* sums,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pred || !dims || !terms || !sums || !indices || n_terms < 1 || n_terms > PDE_AMD_MAX_TERMS || outer < 0) return PDE_AMD_EINVAL;
+  if (!workspace || workspace_bytes < pde_amd_terms_workspace_bytes(n_terms)) return PDE_AMD_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)workspace;
+  BlockTable blk;
+  int* blk_start = blk.start;
+  for (int k = 0; k <= PDE_AMD_MAX_TERMS; ++k) blk_start[k] = 0;
+  for (int k = 0; k < n_terms; ++k) {
+    TermArgs a;
+    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices);
+    if (rc) return rc;
+    const int nb = a.count > 0 ? term_blocks(a.count) : 0;
+    blk_start[k + 1] = blk_start[k] + nb;
+    if (nb) hipLaunchKernelGGL(term_fwd_kernel, dim3(nb), dim3(256), 0, st, a, partial + blk_start[k]);
+  }
+  hipLaunchKernelGGL(term_finalize_kernel, dim3(1), dim3(64), 0, st, partial, blk, (int)n_terms, sums);
+  return check_launch();
+}
+
+int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                           const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scales,
+                           float* grad, void* stream) {
+  if (!pred || !dims || !terms || !scales || !grad || !indices || n_terms < 1 || n_terms > PDE_AMD_MAX_TERMS || outer < 0) return PDE_AMD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int k = 0; k < n_terms; ++k) {      // one launch per term, in order: terms may overlap each other, a term never overlaps itself
+    TermArgs a;
+    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices);
+    if (rc) return rc;
+    if (a.count > 0) hipLaunchKernelGGL(term_bwd_kernel, dim3(term_blocks(a.count)), dim3(256), 0, st, a, scales + k, grad);
+  }
+  return check_launch();
+}
+
+static int fill_gather(GatherArgs& a, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C, const int32_t* channels,
+                       int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose) {
+  if (B < 0 || T_out < 0 || T_in < 1 || S < 0 || C < 1 || !channels || n_fields < 1 || n_fields > PDE_AMD_MAX_FIELDS) return PDE_AMD_EINVAL;
+  if (transpose && (rows < 1 || cols < 1 || S % ((long)rows * cols) != 0)) return PDE_AMD_ESHAPE;
+  a.nf = n_fields; a.C = C; a.B = B; a.T_out = T_out; a.T_in = T_in; a.S = S;
+  a.rows = rows; a.cols = cols; a.transpose = transpose;
+  for (int f = 0; f < n_fields; ++f) {
+    if (channels[f] < 0 || channels[f] >= C) return PDE_AMD_EINVAL;
+    a.ch[f] = channels[f];
+  }
+  return PDE_AMD_OK;
+}
+
+int pde_amd_gather_fields(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
+                          const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                          float* const* fields, void* stream) {
+  GatherArgs a;
+  const int rc = fill_gather(a, B, T_out, T_in, S, C, channels, n_fields, rows, cols, transpose);
+  if (rc) return rc;
+  if (!output || !input || !fields) return PDE_AMD_EINVAL;
+  a.output = output; a.input = input;
+  for (int f = 0; f < n_fields; ++f) { if (!fields[f]) return PDE_AMD_EINVAL; a.fields[f] = fields[f]; }
+  const long npts = B * (T_out + 1) * S;
+  if (npts == 0) return PDE_AMD_OK;
+  long nb = (npts + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int64_t T_out, int64_t S, int32_t C,
+                                const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                                float* grad_output, void* stream) {
+  GatherArgs a;
+  const int rc = fill_gather(a, B, T_out, 1, S, C, channels, n_fields, rows, cols, transpose);
+  if (rc) return rc;
+  if (!field_grads || !grad_output) return PDE_AMD_EINVAL;
+  for (int f = 0; f < n_fields; ++f) { if (!field_grads[f]) return PDE_AMD_EINVAL; a.gfields[f] = field_grads[f]; }
+  const long n = B * T_out * S * (long)C;
+  if (n == 0) return PDE_AMD_OK;
+  if (reinterpret_cast<uintptr_t>(grad_output) & 15) return PDE_AMD_EINVAL;
+  long nb = ((n + 3) / 4 + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, grad_output, n);
+  return check_launch();
+}
+
+}  // extern "C"

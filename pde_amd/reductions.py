@@ -1,0 +1,123 @@
+"""Raw device primitives behind the metrics, boundary losses and glue: thin wrappers over the C ABI.
+
+  pair_stats(pred, target, groups, rows, channels, rse_eps) -> fp64 [groups, channels, NSTAT]
+  terms_forward(pred, target, outer, dims, terms, indices)  -> fp64 [n_terms]
+  terms_backward(pred, target, outer, dims, terms, indices, scales, grad)   (accumulates into grad)
+  gather_fields(output, input, channels, transpose)         -> list of [B, T_out + 1, *spatial] tensors
+  scatter_field_grads(grads, out_shape, channels, transpose) -> [B, T_out, *spatial, C]
+
+Everything runs on the current torch HIP stream; there is no CPU path in this module.  The CPU tests
+replace the backend object with an interpreter that lives under tests/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import _lib
+
+NSTAT = _lib.NSTAT
+S_D2, S_G2, S_G, S_P, S_RSE, S_MAXD = range(6)
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"pde_amd: {what} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class HipReductions:
+    name = "hip"
+
+    def pair_stats(self, pred, target, groups: int, rows: int, channels: int, rse_eps: float = 1e-8):
+        l = _lib.lib()
+        pred, target = _f32c(pred, "pred"), _f32c(target, "target")
+        if pred.numel() != groups * rows * channels or target.numel() != pred.numel():
+            raise ValueError(f"pair_stats: {tuple(pred.shape)} / {tuple(target.shape)} is not [{groups}, {rows}, {channels}]")
+        stats = torch.empty((groups, channels, NSTAT), dtype=torch.float64, device=pred.device)
+        nbytes = l.pde_amd_pair_stats_workspace_bytes(groups, rows, channels)
+        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
+        _lib.check(l.pde_amd_pair_stats(pred.data_ptr(), target.data_ptr(), groups, rows, channels, float(rse_eps),
+                                        stats.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "pair_stats")
+        return stats
+
+    @staticmethod
+    def _term_array(terms: Sequence["_lib.Term"]):
+        arr = (_lib.Term * len(terms))()
+        for i, t in enumerate(terms):
+            arr[i] = t
+        return arr
+
+    def terms_forward(self, pred, target, outer: int, dims: Sequence[int], terms, indices):
+        l = _lib.lib()
+        sums = torch.empty(len(terms), dtype=torch.float64, device=pred.device)
+        nbytes = l.pde_amd_terms_workspace_bytes(len(terms))
+        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
+        d = (C.c_int32 * 4)(*[int(v) for v in dims])
+        _lib.check(l.pde_amd_terms_forward(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
+                                           self._term_array(terms), len(terms), indices.data_ptr(), sums.data_ptr(),
+                                           ws.data_ptr(), nbytes, _stream(pred)), "terms_forward")
+        return sums
+
+    def terms_backward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, scales, grad):
+        l = _lib.lib()
+        d = (C.c_int32 * 4)(*[int(v) for v in dims])
+        _lib.check(l.pde_amd_terms_backward(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
+                                            self._term_array(terms), len(terms), indices.data_ptr(), scales.data_ptr(),
+                                            grad.data_ptr(), _stream(pred)), "terms_backward")
+        return grad
+
+    def gather_fields(self, output, input_data, channels: Sequence[int], transpose: bool) -> List[torch.Tensor]:
+        l = _lib.lib()
+        B, T_out, T_in = output.shape[0], output.shape[1], input_data.shape[1]
+        spatial = list(output.shape[2:-1])
+        Cn = output.shape[-1]
+        S = 1
+        for v in spatial:
+            S *= v
+        rows, cols = (spatial[-2], spatial[-1]) if len(spatial) >= 2 else (1, 1)
+        fshape = spatial[:-2] + [cols, rows] if transpose else spatial
+        fields = [torch.empty([B, T_out + 1] + fshape, dtype=torch.float32, device=output.device) for _ in channels]
+        ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
+        _lib.check(l.pde_amd_gather_fields(output.data_ptr(), input_data.data_ptr(), B, T_out, T_in, S, Cn, ch, len(channels),
+                                           rows, cols, int(bool(transpose)), _lib.ptr_array(fields, len(fields)), _stream(output)),
+                   "gather_fields")
+        return fields
+
+    def scatter_field_grads(self, grads, out_shape, channels: Sequence[int], transpose: bool):
+        l = _lib.lib()
+        B, T_out = out_shape[0], out_shape[1]
+        spatial = list(out_shape[2:-1])
+        Cn = out_shape[-1]
+        S = 1
+        for v in spatial:
+            S *= v
+        rows, cols = (spatial[-2], spatial[-1]) if len(spatial) >= 2 else (1, 1)
+        gout = torch.empty(list(out_shape), dtype=torch.float32, device=grads[0].device)
+        ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
+        _lib.check(l.pde_amd_scatter_field_grads(_lib.ptr_array(grads, len(grads)), B, T_out, S, Cn, ch, len(channels),
+                                                 rows, cols, int(bool(transpose)), gout.data_ptr(), _stream(gout)),
+                   "scatter_field_grads")
+        return gout
+
+
+_backend = HipReductions()
+
+
+def set_backend(b):
+    """Swap the primitive provider (tests install a CPU interpreter); returns the previous one."""
+    global _backend
+    old, _backend = _backend, b
+    return old
+
+
+def get_backend():
+    return _backend

@@ -1,0 +1,158 @@
+"""Shared bodies of the glue / metric parity tests: the same checks run against the CPU interpreter backend
+(-m "not gpu") and against the HIP library on the device (-m gpu)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import glue_oracle as GO
+from pde_amd import boundary as PB
+from pde_amd import glue as PG
+from pde_amd import metrics as PM
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-5      # fp32 product path against fp64 golden values
+
+
+def gold():
+    return np.load(os.path.join(GOLD, "glue.npz"))
+
+
+def _rel(a, b):
+    """relative L2 distance; NaNs (empty Fourier bands of the reference) must sit at the same places"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    a, b = np.nan_to_num(a), np.nan_to_num(b)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _t(x, dev, grad=False):
+    t = torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    return t.requires_grad_(True) if grad else t
+
+
+BOUNDARY = {
+    "bc_strip_w1": ("pred", "target", lambda p, g, m: PB.compute_boundary_loss(p, g, m, 1)),
+    "bc_strip_w2": ("pred", "target", lambda p, g, m: PB.compute_boundary_loss(p, g, m, 2)),
+    "bc_edge": ("pred", "target", lambda p, g, m: PB.compute_boundary_loss(p, g, m, variant="edges")),
+    "bc_1d": ("pred1d", "target1d", lambda p, g, m: PB.compute_boundary_loss(p, g, m)),
+    "bc_3d_faces": ("pred3d", "target3d", lambda p, g, m: PB.compute_boundary_loss(p, g, m, variant="faces")),
+    "bc_3d_shells": ("pred3d", "target3d", lambda p, g, m: PB.compute_boundary_loss(p, g, m)),
+    "noslip": ("pred", None, lambda p, g, m: PB.compute_noslip_loss(p)),
+    "patch": ("pred_patch", None, lambda p, g, m: PB.compute_patch_boundary_loss(p, m)),
+}
+
+
+def check_boundary(name, dev):
+    d = gold()
+    pk, gk, fn = BOUNDARY[name]
+    p = _t(d[pk], dev, grad=True)
+    g = _t(d[gk], dev) if gk else None
+    m = torch.tensor(d["mask"], device=dev)
+    val = fn(p, g, m)
+    assert val.dim() == 0 and val.dtype == torch.float32
+    val.backward()
+    assert abs(float(val.detach()) - float(d[name])) <= RTOL * abs(float(d[name])), (float(val.detach()), float(d[name]))
+    assert _rel(p.grad.cpu().numpy(), d[name + "_grad"]) <= RTOL
+    # exactly the reference's sparsity: zero wherever the reference gradient is zero
+    assert np.array_equal(p.grad.cpu().numpy() != 0, d[name + "_grad"] != 0)
+
+
+def check_boundary_scaled_upstream(dev):
+    """the loss is used as lambda_bc * bc_loss + ...: the upstream gradient is not 1"""
+    d = gold()
+    p = _t(d["pred"], dev, grad=True)
+    val = PB.compute_boundary_loss(p, _t(d["target"], dev), torch.tensor(d["mask"], device=dev), 2)
+    (0.25 * val * val).backward()
+    expect = 0.5 * float(d["bc_strip_w2"]) * d["bc_strip_w2_grad"]
+    assert _rel(p.grad.cpu().numpy(), expect) <= RTOL
+
+
+def check_metrics(dev):
+    d = gold()
+    p, g, m = _t(d["pred"], dev), _t(d["target"], dev), torch.tensor(d["mask"], device=dev)
+    v, r = PM.compute_vrmse(p, g, m)
+    assert abs(float(v) - float(d["vrmse"])) <= RTOL * float(d["vrmse"])
+    assert abs(float(r) - float(d["rmse"])) <= RTOL * float(d["rmse"])
+    s = PM.nrmse_per_sample(p[:, 0, ..., 3], g[:, 0, ..., 3])
+    assert _rel(s.cpu().numpy(), d["nrmse_per_sample"]) <= RTOL
+    pc = PM.nrmse_per_channel(p[:, 0], g[:, 0], [(0, "vx"), (1, "vy"), (15, "p")])
+    assert list(pc) == ["vx", "vy", "p"]
+    assert _rel(np.stack([pc[k].cpu().numpy() for k in pc]), d["nrmse_per_channel"]) <= RTOL
+    assert _rel(PM.compute_rse(p[..., :3], g[..., :3]).cpu().numpy(), d["rse"]) <= 1e-4
+    mr = PM.compute_mean_rse(p[..., :3], g[..., :3])
+    assert isinstance(mr, float) and abs(mr - float(d["mean_rse"])) <= 1e-4 * float(d["mean_rse"])
+
+
+def check_accumulator(dev):
+    gen = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 3, 6, 5, 18, generator=gen), torch.randn(2, 3, 6, 5, 18, generator=gen)) for _ in range(3)]
+    mask = torch.zeros(2, 18)
+    mask[:, [0, 1, 15]] = 1
+    want = GO.eval_nrmse([(p.double(), g.double(), mask) for p, g in batches], per_timestep=True)
+    acc = PM.NRMSEAccumulator(per_timestep=True)
+    for p, g in batches:
+        acc.update(p.to(dev), g.to(dev), mask.to(dev))
+    got = acc.result()
+    assert got["num_samples"] == want["num_samples"] == 6
+    for key in ("per_channel_nrmse", "per_channel_rmse", "per_channel_gt_rms"):
+        assert sorted(got[key]) == sorted(want[key]) == [0, 1, 15]
+        for c in want[key]:
+            assert abs(got[key][c] - want[key][c]) <= RTOL * want[key][c]
+    assert abs(got["overall_nrmse"] - want["overall_nrmse"]) <= RTOL * want["overall_nrmse"]
+    for c in want["per_timestep_nrmse"]:
+        assert _rel(got["per_timestep_nrmse"][c], want["per_timestep_nrmse"][c]) <= RTOL
+
+
+def check_metric_func(dev, tag):
+    d = np.load(os.path.join(GOLD, "metric_func.npz"))
+    p, g = _t(d[f"{tag}_pred"], dev), _t(d[f"{tag}_target"], dev)
+    for mode, if_mean in (("mean", True), ("full", False)):
+        res = PM.metric_func(p, g, if_mean=if_mean, Lx=1.0, Ly=1.0, Lz=1.0, iLow=2, iHigh=4)
+        assert len(res) == 7
+        for i, r in enumerate(res):
+            want = d[f"{tag}_{mode}_{i}"]
+            assert tuple(r.shape) == tuple(want.shape), (tag, mode, i, r.shape, want.shape)
+            assert _rel(r.cpu().numpy(), want) <= 2e-5, (tag, mode, i, _rel(r.cpu().numpy(), want))
+
+
+def check_gather(dev, transpose):
+    gen = torch.Generator().manual_seed(11)
+    out = torch.randn(2, 3, 6, 8, 18, generator=gen)
+    inp = torch.randn(2, 4, 6, 8, 18, generator=gen)
+    chans = (0, 1, 15) if not transpose else (0, 1, 3)
+    o = out.clone().to(dev).requires_grad_(True)
+    fields = PG.gather_fields(o, inp.to(dev), chans, transpose=transpose)
+    o64 = out.double().requires_grad_(True)
+    want = GO.gather(o64, inp.double(), chans, transpose)
+    ws = [torch.randn(f.shape, generator=gen) for f in want]
+    for f, w in zip(fields, want):
+        assert f.is_contiguous() and f.dtype == torch.float32
+        assert torch.equal(f.cpu(), w.detach().float())           # a copy: bit-exact
+    sum((f * w.to(dev)).sum() for f, w in zip(fields, ws)).backward()
+    sum((f * w.double()).sum() for f, w in zip(want, ws)).backward()
+    assert torch.equal(o.grad.cpu(), o64.grad.float())
+
+
+def check_compute_pde_loss(dev):
+    """trainer glue end to end: gather -> Taylor-Green residual loss -> gradient w.r.t. the 18-channel output"""
+    import pde_amd
+    from oracle import classes as OC
+    gen = torch.Generator().manual_seed(5)
+    out = torch.randn(2, 4, 16, 16, 18, generator=gen)
+    inp = torch.randn(2, 4, 16, 16, 18, generator=gen)
+    nu = torch.tensor([0.03, 0.08])
+    kw = dict(nx=16, ny=16, dt=0.01)
+    o = out.clone().to(dev).requires_grad_(True)
+    total, losses = PG.compute_pde_loss_taylor_green_2d(o, inp.to(dev), pde_amd.TaylorGreen2DPDELoss(**kw).to(dev), nu.to(dev))
+    total.backward()
+    o64 = out.double().requires_grad_(True)
+    u, v, p = GO.gather(o64, inp.double(), (0, 1, 15))
+    want, _ = OC.build("TaylorGreen2DPDELoss", **kw)(u.double(), v.double(), p.double(), nu=nu.double())
+    want.backward()
+    assert abs(float(total.detach()) - float(want.detach())) <= RTOL * float(want.detach())
+    assert _rel(o.grad.cpu().numpy(), o64.grad.numpy()) <= RTOL
+    cfg = {"pde_type": "taylor_green_2d", "physics": dict(kw, eq_scales=None, unknown_key=1)}
+    fn = PG.create_pde_loss(cfg, dev)
+    t2, _ = PG.compute_pde_loss_generic(o.detach(), inp.to(dev), fn, cfg, {"nu": nu})
+    assert abs(float(t2) - float(want.detach())) <= RTOL * float(want.detach())

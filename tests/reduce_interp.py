@@ -1,0 +1,82 @@
+"""CPU stand-in for pde_amd.reductions.HipReductions (TEST INFRASTRUCTURE ONLY).
+
+Implements the same five primitives with NumPy in fp64 so that the host logic of pde_amd.metrics, pde_amd.boundary
+and pde_amd.glue (term construction, counts, epsilons, autograd wiring) is testable without a GPU.  Installed through
+pde_amd.reductions.set_backend by the CPU tests; never used by the product.
+"""
+import numpy as np
+import torch
+
+from pde_amd import reductions as R
+
+
+def _np(t):
+    return t.detach().cpu().double().numpy()
+
+
+class InterpReductions:
+    name = "interp"
+
+    def pair_stats(self, pred, target, groups, rows, channels, rse_eps=1e-8):
+        p = _np(pred).reshape(groups, rows, channels)
+        g = _np(target).reshape(groups, rows, channels)
+        d = p - g
+        st = np.zeros((groups, channels, R.NSTAT))
+        st[..., R.S_D2] = (d * d).sum(1)
+        st[..., R.S_G2] = (g * g).sum(1)
+        st[..., R.S_G] = g.sum(1)
+        st[..., R.S_P] = p.sum(1)
+        st[..., R.S_RSE] = (d * d / (g * g + rse_eps)).sum(1)
+        st[..., R.S_MAXD] = np.abs(d).max(1) if rows else 0.0
+        return torch.tensor(st, dtype=torch.float64, device=pred.device)
+
+    @staticmethod
+    def _term_offsets(dims, t, pool):
+        lists = [pool[t.idx_off[k]: t.idx_off[k] + t.n[k]] for k in range(4)]
+        strides = [dims[1] * dims[2] * dims[3], dims[2] * dims[3], dims[3], 1]
+        off = np.zeros((1,), dtype=np.int64)
+        for k in range(4):
+            off = (off[:, None] + np.asarray(lists[k], dtype=np.int64)[None, :] * strides[k]).reshape(-1)
+        return off, strides[t.axis]
+
+    def _values(self, pred, target, outer, dims, t, pool):
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        x = _np(pred).reshape(outer, n)
+        if t.use_target:
+            x = x - _np(target).reshape(outer, n)
+        off, ts = self._term_offsets(dims, t, pool)
+        v = np.zeros((outer, off.size))
+        for j in range(t.n_taps):
+            v += t.coef[j] * x[:, off + t.shift[j] * ts]
+        return v, off, ts
+
+    def terms_forward(self, pred, target, outer, dims, terms, indices):
+        pool = indices.cpu().numpy()
+        return torch.tensor([float((self._values(pred, target, outer, dims, t, pool)[0] ** 2).sum()) for t in terms],
+                            dtype=torch.float64, device=pred.device)
+
+    def terms_backward(self, pred, target, outer, dims, terms, indices, scales, grad):
+        pool = indices.cpu().numpy()
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        g = np.zeros((outer, n))
+        sc = scales.detach().cpu().double().numpy()
+        for k, t in enumerate(terms):
+            v, off, ts = self._values(pred, target, outer, dims, t, pool)
+            for j in range(t.n_taps):
+                np.add.at(g, (slice(None), off + t.shift[j] * ts), 2.0 * sc[k] * t.coef[j] * v)
+        grad += torch.tensor(g.reshape(grad.shape), dtype=grad.dtype)
+        return grad
+
+    def gather_fields(self, output, input_data, channels, transpose):
+        out = []
+        for c in channels:
+            f = torch.cat([input_data[:, 0:1, ..., c], output[..., c]], dim=1).float()
+            out.append((f.transpose(-1, -2) if transpose else f).contiguous())
+        return out
+
+    def scatter_field_grads(self, grads, out_shape, channels, transpose):
+        g = torch.zeros(out_shape, dtype=torch.float32)
+        for c, gf in zip(channels, grads):
+            gf = gf.transpose(-1, -2) if transpose else gf
+            g[..., c] += gf[:, 1:]
+        return g

@@ -257,8 +257,8 @@ def run_glue():
     out["nrmse_per_sample"] = f(pred[:, 0, ..., 3], tgt[:, 0, ..., 3]).numpy()
     f2 = load_function("tools/eval_rollout.py", "nrmse_per_channel", dict(nrmse_per_sample=f))
     try:
-        r = f2(pred[:, 0], tgt[:, 0], [0, 1, 15])
-        out["nrmse_per_channel"] = np.asarray([float(x) for x in (r.values() if isinstance(r, dict) else r)])
+        r = f2(pred[:, 0], tgt[:, 0], [(0, "vx"), (1, "vy"), (15, "p")])
+        out["nrmse_per_channel"] = np.stack([r[k].numpy() for k in ("vx", "vy", "p")])
     except Exception as e:
         out["nrmse_per_channel_error"] = np.frombuffer(repr(e).encode(), dtype=np.uint8)
     f = load_function("eval/eval_autoregressive.py", "compute_rse")
@@ -290,6 +290,10 @@ def main():
     import finetune.pde_loss_verified as mod
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if "--only-glue" in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "glue.npz"), **run_glue())
+        print("wrote glue")
+        return
     for name, spec in cases().items():
         np.savez_compressed(os.path.join(OUT, f"pde_{name}.npz"), **run_case(name, spec, mod))
         print("wrote", name)
