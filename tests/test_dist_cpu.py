@@ -1,0 +1,133 @@
+"""world_size-2 gloo tests of the data-parallel path: batch sharding, the packed scalar all-reduce, the cross-rank
+metric accumulators, and sharded-loss == full-batch-loss with the CPU interpreter backends."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pde_amd import dist as pdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as man:
+        ret = man.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, _free_port.port, fn, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        return dict(ret)
+
+
+def _case_reduce(rank, world):
+    vals = {"total": torch.tensor(1.0 + rank), "continuity": torch.tensor(10.0 * (rank + 1))}
+    mean = pdist.reduce_scalars(vals)
+    tot = pdist.reduce_scalars(vals, op="sum")
+    return {k: float(v) for k, v in mean.items()}, {k: float(v) for k, v in tot.items()}
+
+
+def _case_sharded_loss(rank, world):
+    """each rank evaluates its shard of the batch; the mean of rank means equals the full-batch loss (equal shards)"""
+    import pde_amd
+    from pde_amd import functional as PF
+    from tests.spec_interp import InterpBackend
+    PF.set_backend(InterpBackend())
+    g = torch.Generator().manual_seed(0)
+    B = 4
+    fields = [torch.randn(B, 5, 8, 8, generator=g) for _ in range(3)]
+    nu = torch.tensor([0.01, 0.02, 0.05, 0.1])
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01)
+    full, _ = fn(*fields, nu=nu)
+    a, b = pdist.shard_batch(B, rank, world)
+    local, losses = fn(*[f[a:b].contiguous() for f in fields], nu=nu[a:b])
+    red = pdist.reduce_scalars({"total": local, **losses})
+    return float(full), float(red["total"]), (a, b)
+
+
+def _case_accumulator(rank, world):
+    from pde_amd import metrics as PM
+    from pde_amd import reductions as R
+    from tests.reduce_interp import InterpReductions
+    from oracle import glue_oracle as GO
+    R.set_backend(InterpReductions())
+    g = torch.Generator().manual_seed(1)
+    data = [(torch.randn(2, 3, 4, 4, 18, generator=g), torch.randn(2, 3, 4, 4, 18, generator=g)) for _ in range(4)]
+    mask = torch.zeros(18)
+    mask[[0, 5]] = 1
+    acc = PM.NRMSEAccumulator(per_timestep=True)
+    for i, (p, t) in enumerate(data):
+        if i % world == rank:
+            acc.update(p, t, mask)
+    got = acc.result()
+    want = GO.eval_nrmse([(p.double(), t.double(), mask) for p, t in data], per_timestep=True)
+    return got, want
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _port():
+    _free_port.port = _free_port()
+    yield
+
+
+def test_shard_batch_partitions():
+    for n in (0, 1, 7, 16, 64):
+        for world in (1, 2, 3, 8):
+            parts = [pdist.shard_batch(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_packed_all_reduce_world2():
+    _free_port.port = _free_port()
+    ret = _run(_case_reduce)
+    for r in (0, 1):
+        mean, tot = ret[r]
+        assert mean == {"total": 1.5, "continuity": 15.0}
+        assert tot == {"total": 3.0, "continuity": 30.0}
+
+
+def test_sharded_loss_equals_full_batch_world2():
+    _free_port.port = _free_port()
+    ret = _run(_case_sharded_loss)
+    assert ret[0][2] == (0, 2) and ret[1][2] == (2, 4)
+    for r in (0, 1):
+        full, red, _ = ret[r]
+        assert abs(full - red) <= 1e-6 * abs(full)
+
+
+def test_metric_accumulator_world2():
+    _free_port.port = _free_port()
+    ret = _run(_case_accumulator)
+    for r in (0, 1):
+        got, want = ret[r]
+        assert got["num_samples"] == want["num_samples"] == 8
+        for c in want["per_channel_nrmse"]:
+            assert abs(got["per_channel_nrmse"][c] - want["per_channel_nrmse"][c]) <= 1e-6 * want["per_channel_nrmse"][c]
+        for c in want["per_timestep_nrmse"]:
+            for a, b in zip(got["per_timestep_nrmse"][c], want["per_timestep_nrmse"][c]):
+                assert abs(a - b) <= 1e-6 * b
