@@ -104,7 +104,7 @@ int pde_amd_residual_backward(const pde_amd_problem* prob,
  *   compute_mean_rse         eval/eval_autoregressive.py:197-219
  *   metric_func              eval/metrics.py:189-226 (RMSE, nRMSE, MPP-nRMSE, conserved-sum error, max error; there the
  *                            caller passes channels = nt * nc of the PDEBench layout [nb, nx.., nt, nc]).
- * channels <= 1024. */
+ * channels <= 1024, groups <= 65535. */
 #define PDE_AMD_NSTAT 6
 size_t pde_amd_pair_stats_workspace_bytes(int64_t groups, int64_t rows, int32_t channels);
 int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
@@ -153,7 +153,8 @@ int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer
  * with output [B][T_out][S][C], input [B][T_in][S][C], S the product of the spatial extents.  transpose = 1
  * swaps the last two spatial axes (rows x cols -> cols x rows) in the fields, which is what the
  * Rayleigh-Benard trainer's u.transpose(-1, -2) feeds its loss.  The scatter is the gradient of the gather
- * w.r.t. output: every element of grad_output [B][T_out][S][C] is written, zeros outside the gathered channels. */
+ * w.r.t. output: every element of grad_output [B][T_out][S][C] is written, zeros outside the gathered channels
+ * (B * T_out <= 65535, S * C < 2^31). */
 int pde_amd_gather_fields(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
                           const int32_t* channels /* host */, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
                           float* const* fields /* host array of device pointers */, void* stream);

@@ -78,17 +78,25 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
   (void)rows_per_step;
 }
 
-__global__ void pair_stats_finalize_kernel(const double* __restrict__ partial, int blocks_per_group, int C, double* __restrict__ stats) {
-  const int g = blockIdx.x;
-  for (int w = threadIdx.x; w < NSTAT * C; w += blockDim.x) {
-    const int c = w / NSTAT, s = w % NSTAT;
-    double r = 0.0;
-    for (int b = 0; b < blocks_per_group; ++b) {
-      const double v = partial[(((long)g * blocks_per_group + b) * C + c) * NSTAT + s];
-      r = s < 5 ? r + v : fmax(r, v);
-    }
-    stats[((long)g * C + c) * NSTAT + s] = r;
+// one wave per (group, channel, statistic): lanes stride over the workgroups' partials, then a fixed-order shuffle tree
+__global__ __launch_bounds__(256) void pair_stats_finalize_kernel(const double* __restrict__ partial, int blocks_per_group, int C,
+                                                                   double* __restrict__ stats) {
+  const int g = blockIdx.y;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= NSTAT * C) return;
+  const int c = w / NSTAT, s = w % NSTAT, lane = threadIdx.x & 63;
+  const bool is_max = s == 5;
+  double r = 0.0;
+  for (int b = lane; b < blocks_per_group; b += 64) {
+    const double v = partial[(((long)g * blocks_per_group + b) * C + c) * NSTAT + s];
+    r = is_max ? fmax(r, v) : r + v;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double v = __shfl_down(r, o, 64);
+    r = is_max ? fmax(r, v) : r + v;
+  }
+  if (lane == 0) stats[((long)g * C + c) * NSTAT + s] = r;
 }
 
 struct PairPlan {
@@ -110,7 +118,7 @@ inline bool pair_plan(long groups, long rows, int C, PairPlan& pl) {
   if (bpg < 1) bpg = 1;
   pl.steps_per_block = (steps + bpg - 1) / bpg;
   pl.blocks_per_group = (int)((steps + pl.steps_per_block - 1) / pl.steps_per_block);
-  return groups * (long)pl.blocks_per_group < (1L << 31);
+  return groups * (long)pl.blocks_per_group < (1L << 31) && groups <= 65535;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -208,6 +216,12 @@ __device__ __forceinline__ long field_site(const GatherArgs& a, long s) {
   const long lead = s / rc, r = (s % rc) / a.cols, c = s % a.cols;
   return lead * rc + c * a.rows + r;
 }
+__device__ __forceinline__ unsigned field_site(const GatherArgs& a, unsigned s) {      // s < 2^31: inside one frame
+  if (!a.transpose) return s;
+  const unsigned rc = (unsigned)a.rows * (unsigned)a.cols;
+  const unsigned lead = s / rc, rem = s - lead * rc, r = rem / (unsigned)a.cols, c = rem - r * (unsigned)a.cols;
+  return lead * rc + c * (unsigned)a.rows + r;
+}
 
 __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
   const long npts = a.B * (a.T_out + 1) * a.S;
@@ -219,30 +233,31 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
   }
 }
 
-// one thread per float4 of grad_output; every element is written (zeros outside the gathered channels)
-__global__ __launch_bounds__(256) void scatter_kernel(const GatherArgs a, float* __restrict__ grad_output, long n_elems) {
+// grid.y = (b, t) frame of grad_output, grid.x strides over the frame's float4s; all index arithmetic inside a frame
+// is 32-bit.  Every element is written (zeros outside the gathered channels).  VEC = 4 needs S*C % 4 == 0.
+template <int VEC>
+__global__ __launch_bounds__(256) void scatter_kernel(const GatherArgs a, float* __restrict__ grad_output) {
   typedef float f4 __attribute__((ext_vector_type(4)));
-  const long nvec = (n_elems + 3) / 4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    float v[4];
+  const long frame = blockIdx.y;
+  const long b = frame / a.T_out, t = frame % a.T_out;
+  const unsigned n = (unsigned)(a.S * a.C);                 // elements of the frame
+  const unsigned C = (unsigned)a.C;
+  float* dst = grad_output + frame * (long)n;
+  const long fbase = (b * (a.T_out + 1) + t + 1) * a.S;
+  for (unsigned i = (blockIdx.x * 256 + threadIdx.x) * VEC; i < n; i += gridDim.x * 256 * VEC) {
+    float v[VEC];
+    const unsigned pt0 = i / C;
+    unsigned c = i - pt0 * C, pt = pt0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long e = 4 * i + k;
+    for (int k = 0; k < VEC; ++k) {
       float r = 0.0f;
-      if (e < n_elems) {
-        const int c = (int)(e % a.C);
-        const long pt = e / a.C;
-        for (int f = 0; f < a.nf; ++f) {
-          if (a.ch[f] == c) {
-            const long s = pt % a.S, t = (pt / a.S) % a.T_out, b = pt / (a.S * a.T_out);
-            r += a.gfields[f][(b * (a.T_out + 1) + t + 1) * a.S + field_site(a, s)];
-          }
-        }
-      }
+      for (int f = 0; f < a.nf; ++f)
+        if ((unsigned)a.ch[f] == c) r += a.gfields[f][fbase + field_site(a, pt)];
       v[k] = r;
+      if (++c == C) { c = 0; ++pt; }
     }
-    if (4 * i + 3 < n_elems) *reinterpret_cast<f4*>(grad_output + 4 * i) = f4{v[0], v[1], v[2], v[3]};
-    else for (int k = 0; k < 4 && 4 * i + k < n_elems; ++k) grad_output[4 * i + k] = v[k];
+    if (VEC == 4) *reinterpret_cast<f4*>(dst + i) = f4{v[0], v[1], v[2], v[3]};
+    else dst[i] = v[0];
   }
 }
 
@@ -277,7 +292,8 @@ int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, i
   const size_t lds = (size_t)NSTAT * pl.nt * sizeof(double);
   hipLaunchKernelGGL(pair_stats_kernel, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
                      (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, partial);
-  hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)groups), dim3(128), 0, st, partial, pl.blocks_per_group, (int)channels, stats);
+  hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)((NSTAT * channels + 3) / 4), (unsigned)groups), dim3(256), 0, st, partial,
+                     pl.blocks_per_group, (int)channels, stats);
   return check_launch();
 }
 
@@ -377,10 +393,14 @@ int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int6
   for (int f = 0; f < n_fields; ++f) { if (!field_grads[f]) return PDE_AMD_EINVAL; a.gfields[f] = field_grads[f]; }
   const long n = B * T_out * S * (long)C;
   if (n == 0) return PDE_AMD_OK;
-  if (reinterpret_cast<uintptr_t>(grad_output) & 15) return PDE_AMD_EINVAL;
-  long nb = ((n + 3) / 4 + 255) / 256;
-  if (nb > 65536) nb = 65536;
-  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, grad_output, n);
+  const long frame_elems = S * (long)C;
+  if (frame_elems >= (1L << 31) || B * T_out > 65535) return PDE_AMD_ESHAPE;
+  const bool vec = frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_output) & 15) == 0;
+  long nbx = (frame_elems / (vec ? 4 : 1) + 256 * 8 - 1) / (256 * 8);      // about 8 stores per thread
+  if (nbx > 4096) nbx = 4096;
+  const dim3 grid((unsigned)nbx, (unsigned)(B * T_out));
+  if (vec) hipLaunchKernelGGL(scatter_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a, grad_output);
+  else hipLaunchKernelGGL(scatter_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, grad_output);
   return check_launch();
 }
 

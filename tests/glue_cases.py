@@ -116,10 +116,10 @@ def check_metric_func(dev, tag):
             assert _rel(r.cpu().numpy(), want) <= 2e-5, (tag, mode, i, _rel(r.cpu().numpy(), want))
 
 
-def check_gather(dev, transpose):
+def check_gather(dev, transpose, spatial=(6, 8)):
     gen = torch.Generator().manual_seed(11)
-    out = torch.randn(2, 3, 6, 8, 18, generator=gen)
-    inp = torch.randn(2, 4, 6, 8, 18, generator=gen)
+    out = torch.randn(2, 3, *spatial, 18, generator=gen)
+    inp = torch.randn(2, 4, *spatial, 18, generator=gen)
     chans = (0, 1, 15) if not transpose else (0, 1, 3)
     o = out.clone().to(dev).requires_grad_(True)
     fields = PG.gather_fields(o, inp.to(dev), chans, transpose=transpose)

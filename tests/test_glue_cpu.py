@@ -96,6 +96,11 @@ def test_gather_host_logic(transpose):
     GC.check_gather(CPU, transpose)
 
 
+def test_gather_3d_and_1d_host_logic():
+    GC.check_gather(CPU, False, (3, 4, 5))
+    GC.check_gather(CPU, False, (9,))
+
+
 def test_compute_pde_loss_host_logic():
     GC.check_compute_pde_loss(CPU)
 

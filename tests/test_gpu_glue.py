@@ -47,6 +47,11 @@ def test_gather(transpose):
     GC.check_gather(DEV, transpose)
 
 
+@pytest.mark.parametrize("spatial", [(5, 7), (3, 4, 5), (9,)])
+def test_gather_odd_extents(spatial):
+    GC.check_gather(DEV, len(spatial) == 2, spatial)
+
+
 def test_compute_pde_loss():
     GC.check_compute_pde_loss(DEV)
 

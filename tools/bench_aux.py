@@ -1,0 +1,55 @@
+"""Timing of the metric / boundary / glue kernels at rollout-evaluation sizes (HIP events, algorithmic bytes)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pde_amd
+from pde_amd import reductions as R
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+M, H, W, C = 64, 512, 128, 18
+p = torch.randn(M, H, W, C, device=dev)
+g = torch.randn(M, H, W, C, device=dev)
+be = R.get_backend()
+nbytes = 8 * p.numel()
+for groups in (1, M):
+    ms = timeit(lambda: be.pair_stats(p, g, groups, p.numel() // (groups * C), C))
+    print(f"pair_stats [{M},{H},{W},{C}] groups={groups}: {ms:.3f} ms  {nbytes / ms / 1e6:.0f} GB/s algorithmic (8 B/element)")
+mask = torch.zeros(C, device=dev); mask[[0, 1, 3]] = 1
+ms = timeit(lambda: pde_amd.compute_vrmse(p, g, mask))
+print(f"compute_vrmse incl. host epilogue: {ms:.3f} ms")
+ms = timeit(lambda: torch.mean((p[..., [0, 1, 3]] - g[..., [0, 1, 3]]) ** 2))
+print(f"torch mse on 3 gathered channels (one of the reference's 7 reductions): {ms:.3f} ms")
+
+B, T = 16, 15
+out = torch.randn(B, T, 256, 256, C, device=dev, requires_grad=True)
+inp = torch.randn(B, 1, 256, 256, C, device=dev)
+ms = timeit(lambda: pde_amd.gather_fields(out, inp, (0, 1, 15)))
+rd = 4 * (out.numel() + inp.numel())
+print(f"gather_fields 3 of 18 channels [{B},{T},256,256,18]: {ms:.3f} ms  ({rd / ms / 1e6:.0f} GB/s of full-row reads)")
+fields = pde_amd.gather_fields(out, inp, (0, 1, 15))
+gr = [torch.randn_like(f) for f in fields]
+ms = timeit(lambda: R.get_backend().scatter_field_grads(gr, tuple(out.shape), (0, 1, 15), False))
+print(f"scatter_field_grads: {ms:.3f} ms  ({4 * out.numel() / ms / 1e6:.0f} GB/s of gradient writes)")
+tgt = torch.randn(B, T, 256, 256, C, device=dev)
+m2 = torch.zeros(B, C, device=dev); m2[:, [0, 1, 15]] = 1
+o2 = out.detach().requires_grad_(True)
+def bc():
+    o2.grad = None
+    pde_amd.compute_boundary_loss(o2, tgt, m2, 1).backward()
+ms = timeit(bc)
+print(f"compute_boundary_loss fwd+bwd (includes zero-filling the {4 * out.numel() / 1e6:.0f} MB gradient): {ms:.3f} ms")
