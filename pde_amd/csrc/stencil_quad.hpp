@@ -136,9 +136,9 @@ struct RingAccQ : SiteBase<P> {
 template <class P, int W>
 struct QuadCfg {
   static_assert(W == 2 || W == 4, "lane width");
-  // the same tile is covered by 4/W times the lanes, each with about W/4 of the registers
+  // the same tile is covered by 4/W times the lanes
   static constexpr int NT = P::NTQ * 4 / W;
-  static constexpr int WPS = P::WPSQ * 4 / W;
+  static constexpr int WPS = P::WPSQ;          // waves per SIMD the adjoint is compiled for
   // forward tile
   using TL = Tile<P::QF0, P::QF1, P::QF2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), padw<W>(cmax(P::RH2, P::RT2))>;
   using TXF = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, padw<W>(P::XH2)>;
@@ -475,16 +475,24 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
 #ifdef PDE_AMD_SKEW
   if ((blockIdx.x / 256) & 1) { for (int i = 0; i < PDE_AMD_SKEW; ++i) __builtin_amdgcn_s_sleep(16); }
 #endif
+  // DEEP = false (PDEs whose adjoint already fills the register file): one set, fetched at the top of the step
+  // that stores it.
+  constexpr bool DEEP = P::QPD >= 2;
   fv stage_a[P::NF][ST::EPT], stage_b[P::NF][ST::EPT];
+  if (DEEP) {
 #pragma unroll
-  for (int f = 0; f < P::NF; ++f) st.fetch(stage_b[f], fb[f] + (long)min(n0 + 2, g.T - 1) * g.S);
+    for (int f = 0; f < P::NF; ++f) st.fetch(stage_b[f], fb[f] + (long)min(n0 + 2, g.T - 1) * g.S);
+  }
 
   auto step = [&](const int n, fv (&stage_new)[P::NF][ST::EPT], fv (&stage)[P::NF][ST::EPT]) __attribute__((always_inline)) {
     const int fnew = n + 2;
     const bool more = n < qb && fnew < g.T;
     PDE_AMD_STAMP(0);
 #pragma unroll
-    for (int f = 0; f < P::NF; ++f) st.fetch(stage_new[f], fb[f] + (long)min(n + 3, g.T - 1) * g.S);
+    for (int f = 0; f < P::NF; ++f) {
+      if (DEEP) st.fetch(stage_new[f], fb[f] + (long)min(n + 3, g.T - 1) * g.S);
+      else st.fetch(stage[f], fb[f] + (long)min(n + 2, g.T - 1) * g.S);
+    }
     PDE_AMD_STAMP(1);
 
     // G(n) = coef * R(n) on the tile plus the adjoint's reach
@@ -621,7 +629,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   // half's loads are still in flight at the loop head, and it would drain the memory queue there.
   for (int n = n0; n <= qb; n += 2) {
     step(n, stage_a, stage_b);
-    step(n + 1, stage_b, stage_a);
+    step(n + 1, stage_b, stage_a);      // without DEEP the sets are independent scratch and one of them is optimised away
   }
 }
 

@@ -47,6 +47,7 @@ class Spec:
     waves_per_simd_quad: int = 2
     quad_width_fwd: int = 4
     quad_width_bwd: int = 4
+    quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
 
     # derived
     def analyse(self):
@@ -121,7 +122,7 @@ def _reg(s: Spec):
 
 T1D = dict(tile_fwd=(1, 1, 256), tile_bwd=(1, 1, 256), threads=256, quad_fwd=(1, 1, 256), quad_bwd=(1, 1, 256), threads_quad=64)
 T3D = dict(tile_fwd=(2, 4, 64), tile_bwd=(4, 8, 64), threads=256, quad_fwd=(2, 8, 64), quad_bwd=(2, 8, 64), threads_quad=256)
-T2D_WIDE = dict(tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64), quad_fwd=(1, 8, 64), quad_bwd=(1, 8, 64), threads_quad=128, quad_width_fwd=2, quad_width_bwd=2)   # 4-field PDEs
+T2D_WIDE = dict(tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64), quad_fwd=(1, 8, 64), quad_bwd=(1, 8, 64), threads_quad=128, quad_width_fwd=2, quad_width_bwd=2, quad_prefetch=1)   # 4-field PDEs
 
 
 # ---- 1-D periodic family -----------------------------------------------------------------------
@@ -288,7 +289,7 @@ def _burgers2d_ch():
     ru = _ddt(b, u) + conv(u) - u * div - nu * lap(u)
     rv = _ddt(b, v) + conv(v) - v * div - nu * lap(v)
     irr = _d1c4(b, v, 2, "dx") - _d1c4(b, u, 1, "dy")
-    return b.done([ru, rv, irr], quad_width_bwd=2)
+    return b.done([ru, rv, irr], quad_width_bwd=2, quad_prefetch=1)
 
 
 def _active_matter():
@@ -336,7 +337,7 @@ def _turbulent_radiative():
     mass = _ddt(b, rho) + dx(rho * vx) + dy(rho * vy)
     xm = _ddt(b, rho * vx) + dx(rho * vx * vx + P) + dy(rho * vx * vy)
     ym = _ddt(b, rho * vy) + dx(rho * vx * vy) + dy(rho * vy * vy + P)
-    return b.done([mass, xm, ym], **T2D_WIDE)
+    return b.done([mass, xm, ym], **{**T2D_WIDE, 'quad_prefetch': 2, 'waves_per_simd_quad': 3})
 
 
 def _wave_gauss():
