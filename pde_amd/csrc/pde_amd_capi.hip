@@ -116,9 +116,35 @@ struct Ops {
         if (!resid_out[k]) return PDE_AMD_EINVAL;
         a.rout[k] = resid_out[k];
       }
-      items = tr * tiles;
-      if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
-      hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
+      bool launched = false;
+      if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
+        if (p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
+            (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
+          fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
+          const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+          a.chunk = pick_chunk(p->batch * qtiles, (int)tr);
+          items = cdiv((int)tr, a.chunk) * qtiles;
+          if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+          hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF, true>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
+          launched = true;
+        }
+      }
+      if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK) {
+        if (!launched && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
+            (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
+          fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
+          items = tr * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+          if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+          if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+          hipLaunchKernelGGL((fwd_frame_q_kernel<P, P::QWF, true>), dim3((unsigned)(p->batch * items)), dim3(FrameCfg<P, P::QWF>::NT), 0, stream, a);
+          launched = true;
+        }
+      }
+      if (!launched) {
+        items = tr * tiles;
+        if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+        hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
+      }
     } else if (QuadCfg<P, P::QWF>::FWD_OK && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
                (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
       if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
@@ -127,7 +153,16 @@ struct Ops {
         a.chunk = pick_chunk(p->batch * qtiles, (int)tr);
         items = cdiv((int)tr, a.chunk) * qtiles;
         if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
-        hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
+        hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF, false>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
+      }
+    } else if (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
+               (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
+      if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK) {
+        fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
+        items = tr * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+        if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+        if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+        hipLaunchKernelGGL((fwd_frame_q_kernel<P, P::QWF, false>), dim3((unsigned)(p->batch * items)), dim3(FrameCfg<P, P::QWF>::NT), 0, stream, a);
       }
     } else if constexpr (FwdMarchFits<P>::value) {
       a.chunk = pick_chunk(p->batch * tiles, (int)tr);
@@ -178,9 +213,22 @@ struct Ops {
         if (!resid_in[k]) return PDE_AMD_EINVAL;
         a.r[k] = resid_in[k];
       }
-      const long nwg = (long)p->batch * p->frames * tiles;
-      if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
-      hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+      bool launched = false;
+      if constexpr (StoredCfg<P, P::QWB>::OK) {
+        if (p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) && aligned_vec<P::NF, P::QWB>(grads) &&
+            aligned_vec<P::NE, P::QWB>(resid_in) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
+          fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);
+          const long nwgq = (long)p->batch * p->frames * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+          if (nwgq >= (1L << 31)) return PDE_AMD_ESHAPE;
+          hipLaunchKernelGGL((bwd_stored_q_kernel<P, P::QWB>), dim3((unsigned)nwgq), dim3(StoredCfg<P, P::QWB>::NT), 0, stream, a);
+          launched = true;
+        }
+      }
+      if (!launched) {
+        const long nwg = (long)p->batch * p->frames * tiles;
+        if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+        hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+      }
     } else if (QuadCfg<P, P::QWB>::BWD_OK && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) &&
                aligned_vec<P::NF, P::QWB>(grads) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
       if constexpr (QuadCfg<P, P::QWB>::BWD_OK) {

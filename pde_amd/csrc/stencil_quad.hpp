@@ -165,7 +165,7 @@ struct QuadCfg {
 // ------------------------------------------------------------------------------------------------
 // forward, marching, quads: workgroup = (sample, chunk of residual frames, tile)
 // ------------------------------------------------------------------------------------------------
-template <class P, int W>
+template <class P, int W, bool WRITE_R>
 __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const Args a) {
   using C = QuadCfg<P, W>;
   using fv = typename VecOf<W>::type;
@@ -286,6 +286,16 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
       for (int px = 0; px < W; ++px)
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) part[k] += Rq[px][k] * Rq[px][k];
+      if (WRITE_R && pi0[q] < g.N0 && pi1[q] < g.N1 && pi2[q] < g.N2) {      // stored mode: residuals on the full grid, zeros off the lattice
+        const long ro = ((long)b * g.TR + (tau - P::TLO)) * g.S + ((long)pi0[q] * g.N1 + pi1[q]) * g.N2 + pi2[q];
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) {
+          fv r;
+#pragma unroll
+          for (int px = 0; px < W; ++px) r[px] = Rq[px][k];
+          *reinterpret_cast<fv*>(a.rout[k] + ro) = r;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < P::NE; ++k) sum[k] += (double)part[k] * (double)wk[k];
     }
@@ -630,6 +640,350 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   for (int n = n0; n <= qb; n += 2) {
     step(n, stage_a, stage_b);
     step(n + 1, stage_b, stage_a);      // without DEEP the sets are independent scratch and one of them is optimised away
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, one residual frame per workgroup, quads: for PDEs whose time ring of halo tiles does not fit LDS
+// (3-D halos).  The frame's tile + halo is staged in LDS; the neighbouring frames are staged with the (smaller)
+// halo they need, or, when they need none, read as one vector per field straight from global memory.
+// ------------------------------------------------------------------------------------------------
+template <class P, int W>
+struct FrameCfg {
+  static constexpr int NT = P::NTQ * 4 / W;
+  using TL = Tile<P::QF0, P::QF1, P::QF2, P::RH0, P::RH1, padw<W>(P::RH2)>;
+  using TT = Tile<P::QF0, P::QF1, P::QF2, P::RT0, P::RT1, padw<W>(P::RT2)>;
+  using TX = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, padw<W>(P::XH2)>;
+  static constexpr bool TT_ON = (P::RT0 | P::RT1 | P::RT2) != 0;
+  static constexpr int NTS = P::TLO + P::THI;
+  static constexpr long BYTES = 4L * (P::NF * TL::SIZE + (TT_ON ? NTS * P::NF * TT::SIZE : 0) + (P::NA ? P::NA * TX::SIZE : 0));
+  static constexpr bool OK = BYTES <= LDS_BUDGET && P::QF2 % W == 0 && (P::QF0 * P::QF1 * (P::QF2 / W)) % NT == 0 &&
+                             NT % (P::QF2 / W) == 0 && NT <= 1024;
+};
+
+template <class P, class TL, class TT, class TX, int W>
+struct FrameAccQ : SiteBase<P> {
+  using fv = typename VecOf<W>::type;
+  static constexpr int NTS = P::TLO + P::THI;
+  const float* lds;
+  const float* ldst;
+  const float* ldsx;
+  fv fc[NTS > 0 ? NTS : 1][MAXF];     // this quad at the other frames when they need no halo
+  int px;
+  __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
+    if (ot == 0) {
+      PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+      const fv v = *reinterpret_cast<const fv*>(lds + f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + W * qd);
+      return v[e];
+    }
+    const int slot = ot < 0 ? ot + P::TLO : ot + P::TLO - 1;
+    if ((P::RT0 | P::RT1 | P::RT2) != 0) {
+      PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+      const fv v = *reinterpret_cast<const fv*>(ldst + (slot * P::NF + f) * TT::SIZE + o0 * TT::S0 + o1 * TT::S1 + W * qd);
+      return v[e];
+    }
+    return fc[slot][f][px];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const fv v = *reinterpret_cast<const fv*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + W * qd);
+    return v[e];
+  }
+  __device__ __forceinline__ float G(int, int, int, int, int) const { return 0.0f; }
+};
+
+template <class P, int W, bool WRITE_R>
+__global__ __launch_bounds__((FrameCfg<P, W>::NT)) void fwd_frame_q_kernel(const Args a) {
+  using C = FrameCfg<P, W>;
+  using TL = typename C::TL;
+  using TT = typename C::TT;
+  using TX = typename C::TX;
+  using fv = typename VecOf<W>::type;
+  constexpr bool TT_ON = C::TT_ON, AUX_ON = P::NA > 0;
+  constexpr int NT = C::NT, NTS = C::NTS;
+  constexpr int QR = TL::T2 / W;
+  constexpr int QPT = (TL::T0 * TL::T1 * QR) / NT;
+  static_assert(C::OK, "PDE not eligible for the per-frame quad forward");
+
+  __shared__ __attribute__((aligned(16))) float s_f[P::NF * TL::SIZE];
+  __shared__ __attribute__((aligned(16))) float s_t[TT_ON ? NTS * P::NF * TT::SIZE : 4];
+  __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
+  __shared__ double s_red[((NT + 63) / 64) * P::NE];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int tile = w % ntile, rest = w / ntile;
+  const int tr = rest % g.TR, b = rest / g.TR;
+  const int t = tr + P::TLO;
+  const int o2 = (tile % g.nt2) * TL::T2, o1 = ((tile / g.nt2) % g.nt1) * TL::T1, o0 = (tile / (g.nt2 * g.nt1)) * TL::T0;
+  const long frame = ((long)b * g.T + t) * g.S;
+
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) stage_tile<TL, P::PER0, P::PER1, P::PER2, NT, W>(s_f + f * TL::SIZE, a.f[f] + frame, o0, o1, o2, g, 1.0f);
+  if (TT_ON) {
+#pragma unroll
+    for (int s = 0; s < NTS; ++s) {
+      const int ot = s < P::TLO ? s - P::TLO : s - P::TLO + 1;
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f)
+        stage_tile<TT, P::PER0, P::PER1, P::PER2, NT, W>(s_t + (s * P::NF + f) * TT::SIZE, a.f[f] + frame + (long)ot * g.S, o0, o1, o2, g, 1.0f);
+    }
+  }
+  if (AUX_ON) {
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x) stage_tile<TX, P::PER0, P::PER1, P::PER2, NT, W>(s_x + x * TX::SIZE, a.aux[x] + (long)b * g.S, o0, o1, o2, g, 1.0f);
+  }
+  __syncthreads();
+
+  FrameAccQ<P, TL, TT, TX, W> acc;
+  acc.template set_uniforms<true>(a.c, a.sp, b);
+  acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
+  float wk[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) wk[k] = ldc(a.wt, k * g.TR + tr);
+  double sum[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) sum[k] = 0.0;
+
+#pragma unroll
+  for (int q = 0; q < QPT; ++q) {
+    const int row = (threadIdx.x / QR) * QPT + q;
+    const int l2 = W * owned_quad<QR, TL::S1, W>(), l1 = row % TL::T1, l0 = row / TL::T1;
+    const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+    const bool inside = i0 < g.N0 && i1 < g.N1 && i2 < g.N2;
+    const bool rowok = inside && i0 >= g.lo0 && i0 < g.N0 - g.hi0 && i1 >= g.lo1 && i1 < g.N1 - g.hi1;
+    const long goff = inside ? ((long)i0 * g.N1 + i1) * g.N2 + i2 : 0;
+    acc.i0 = i0; acc.i1 = i1;
+    acc.lds = s_f + TL::at(l0, l1, l2);
+    acc.ldst = s_t + TT::at(l0, l1, l2);
+    acc.ldsx = s_x + TX::at(l0, l1, l2);
+    if (!TT_ON) {
+#pragma unroll
+      for (int s = 0; s < NTS; ++s) {
+        const int ot = s < P::TLO ? s - P::TLO : s - P::TLO + 1;
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) acc.fc[s][f] = *reinterpret_cast<const fv*>(a.f[f] + frame + (long)ot * g.S + goff);
+      }
+    }
+    float Rq[W][P::NE];
+#pragma unroll
+    for (int px = 0; px < W; ++px) {
+      acc.px = px; acc.i2 = i2 + px;
+      P::residual(acc, Rq[px]);
+      const bool ok = rowok && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) Rq[px][k] = ok ? Rq[px][k] : 0.0f;
+    }
+    float part[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) {
+      part[k] = 0.0f;
+#pragma unroll
+      for (int px = 0; px < W; ++px) part[k] += Rq[px][k] * Rq[px][k];
+      sum[k] += (double)part[k] * (double)wk[k];
+    }
+    if (WRITE_R && inside) {
+      const long ro = ((long)b * g.TR + tr) * g.S + goff;
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) {
+        fv r;
+#pragma unroll
+        for (int px = 0; px < W; ++px) r[px] = Rq[px][k];
+        *reinterpret_cast<fv*>(a.rout[k] + ro) = r;
+      }
+    }
+  }
+  block_sum_store<P::NE, NT>(sum, s_red, a.partial + (long)w * P::NE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward from stored residuals, quads: workgroup = (sample, output frame, tile).  G = coef * R tiles of the frames
+// the adjoint reaches are staged in LDS with vector loads; other-frame terms that need no halo read their quad
+// straight from global memory.
+// ------------------------------------------------------------------------------------------------
+template <class P, int W>
+struct StoredCfg {
+  static constexpr int NT = P::NTQ * 4 / W;
+  using TG = Tile<P::QB0, P::QB1, P::QB2, P::GH0, P::GH1, padw<W>(P::GH2)>;
+  using TGT = Tile<P::QB0, P::QB1, P::QB2, P::GT0, P::GT1, padw<W>(P::GT2)>;
+  using TA = Tile<P::QB0, P::QB1, P::QB2, P::AH0, P::AH1, padw<W>(P::AH2)>;
+  using TX = Tile<P::QB0, P::QB1, P::QB2, P::XH0, P::XH1, padw<W>(P::XH2)>;
+  static constexpr bool GT_ON = (P::GT0 | P::GT1 | P::GT2) != 0;
+  static constexpr int NGT = P::GTLO + P::GTHI;
+  static constexpr long BYTES = 4L * (P::NE * TG::SIZE + (GT_ON ? NGT * P::NE * TGT::SIZE : 0) + (P::ANY_AF ? P::NF * TA::SIZE : 0) +
+                                      (P::NA ? P::NA * TX::SIZE : 0));
+  static constexpr bool OK = P::ATLO == 0 && P::ATHI == 0 && (P::AT0 | P::AT1 | P::AT2) == 0 && BYTES <= LDS_BUDGET && P::QB2 % W == 0 &&
+                             (P::QB0 * P::QB1 * (P::QB2 / W)) % NT == 0 && NT % (P::QB2 / W) == 0 && NT <= 1024;
+};
+
+template <class P, class TG, class TGT, class TA, class TX, int W>
+struct StoredAdjAccQ : SiteBase<P> {
+  using fv = typename VecOf<W>::type;
+  static constexpr int NG = P::GTLO + P::GTHI + 1;
+  const float* ldsg;
+  const float* ldsgt;
+  const float* ldsa;
+  const float* ldsx;
+  fv gc[NG][MAXE];           // this quad's G at the other frames when those terms need no halo
+  int px;
+  __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
+    if (ot == 0) {
+      PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+      const fv v = *reinterpret_cast<const fv*>(ldsg + k * TG::SIZE + o0 * TG::S0 + o1 * TG::S1 + W * qd);
+      return v[e];
+    }
+    if ((P::GT0 | P::GT1 | P::GT2) != 0) {
+      const int slot = ot < 0 ? ot + P::GTLO : ot + P::GTLO - 1;
+      PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+      const fv v = *reinterpret_cast<const fv*>(ldsgt + (slot * P::NE + k) * TGT::SIZE + o0 * TGT::S0 + o1 * TGT::S1 + W * qd);
+      return v[e];
+    }
+    return gc[ot + P::GTLO][k][px];
+  }
+  __device__ __forceinline__ float F(int f, int, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const fv v = *reinterpret_cast<const fv*>(ldsa + f * TA::SIZE + o0 * TA::S0 + o1 * TA::S1 + W * qd);
+    return v[e];
+  }
+  __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    const fv v = *reinterpret_cast<const fv*>(ldsx + x * TX::SIZE + o0 * TX::S0 + o1 * TX::S1 + W * qd);
+    return v[e];
+  }
+};
+
+template <class TL, bool P0, bool P1, bool P2, int NT, int W>
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int o0, int o1, int o2, const Geom& g, float scale) {
+  using fv = typename VecOf<W>::type;
+  StagerQ<TL, P0, P1, P2, NT, W> st;
+  st.init(o0, o1, o2, g);
+  fv v[StagerQ<TL, P0, P1, P2, NT, W>::EPT];
+  st.fetch(v, src);
+#pragma unroll
+  for (int j = 0; j < StagerQ<TL, P0, P1, P2, NT, W>::EPT; ++j) v[j] = v[j] * scale;
+  st.store(v, tile);
+}
+
+template <class TL, int NT, int W>
+__device__ __forceinline__ void zero_tile_q(float* tile) {
+  using fv = typename VecOf<W>::type;
+  static_assert(TL::SIZE % W == 0, "tile size");
+  for (int i = threadIdx.x; i < TL::SIZE / W; i += NT) *reinterpret_cast<fv*>(tile + W * i) = vec_zero<W>();
+}
+
+template <class P, int W>
+__global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(const Args a) {
+  using C = StoredCfg<P, W>;
+  using TG = typename C::TG;
+  using TGT = typename C::TGT;
+  using TA = typename C::TA;
+  using TX = typename C::TX;
+  using fv = typename VecOf<W>::type;
+  constexpr bool GT_ON = C::GT_ON, AF_ON = P::ANY_AF != 0, AUX_ON = P::NA > 0;
+  constexpr int NT = C::NT, NGT = C::NGT, NG = P::GTLO + P::GTHI + 1;
+  constexpr int QR = TG::T2 / W;
+  constexpr int QPT = (TG::T0 * TG::T1 * QR) / NT;
+  static_assert(C::OK, "PDE not eligible for the quad stored-residual adjoint");
+
+  __shared__ __attribute__((aligned(16))) float s_g[P::NE * TG::SIZE];
+  __shared__ __attribute__((aligned(16))) float s_gt[GT_ON ? NGT * P::NE * TGT::SIZE : 4];
+  __shared__ __attribute__((aligned(16))) float s_a[AF_ON ? P::NF * TA::SIZE : 4];
+  __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
+
+  const Geom& g = a.geo;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = g.nt0 * g.nt1 * g.nt2;
+  const int tile = w % ntile, rest = w / ntile;
+  const int tq = rest % g.T, b = rest / g.T;
+  const int o2 = (tile % g.nt2) * TG::T2, o1 = ((tile / g.nt2) % g.nt1) * TG::T1, o0 = (tile / (g.nt2 * g.nt1)) * TG::T0;
+  const long frame = ((long)b * g.T + tq) * g.S;
+  const int tr0 = tq - P::TLO;
+  const float* rp[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) rp[k] = a.r[k] + (long)b * g.TR * g.S;
+
+  StoredAdjAccQ<P, TG, TGT, TA, TX, W> acc;
+  acc.template set_uniforms<true>(a.c, a.sp, b);
+  acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
+
+  float up[P::NE];
+  upstream_of<P>(a, b, up);
+  float cf[NG][P::NE];
+#pragma unroll
+  for (int s = 0; s < NG; ++s) {
+    const int trs = tr0 + (s - P::GTLO);
+    const bool ok = trs >= 0 && trs < g.TR;
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) cf[s][k] = ok ? up[k] * ldc(a.wt, k * g.TR + max(min(trs, g.TR - 1), 0)) : 0.0f;
+  }
+
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) {
+    const float cfk = cf[P::GTLO][k];      // wave-uniform
+    if (cfk != 0.0f) stage_tile<TG, P::PER0, P::PER1, P::PER2, NT, W>(s_g + k * TG::SIZE, rp[k] + (long)tr0 * g.S, o0, o1, o2, g, cfk);
+    else zero_tile_q<TG, NT, W>(s_g + k * TG::SIZE);
+  }
+  if (GT_ON) {
+#pragma unroll
+    for (int s = 0; s < NGT; ++s) {
+      const int ot = s < P::GTLO ? s - P::GTLO : s - P::GTLO + 1;
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) {
+        const float cfk = cf[ot + P::GTLO][k];
+        float* dst = s_gt + (s * P::NE + k) * TGT::SIZE;
+        if (cfk != 0.0f) stage_tile<TGT, P::PER0, P::PER1, P::PER2, NT, W>(dst, rp[k] + (long)(tr0 + ot) * g.S, o0, o1, o2, g, cfk);
+        else zero_tile_q<TGT, NT, W>(dst);
+      }
+    }
+  }
+  if (AF_ON) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) stage_tile<TA, P::PER0, P::PER1, P::PER2, NT, W>(s_a + f * TA::SIZE, a.f[f] + frame, o0, o1, o2, g, 1.0f);
+  }
+  if (AUX_ON) {
+#pragma unroll
+    for (int x = 0; x < P::NA; ++x) stage_tile<TX, P::PER0, P::PER1, P::PER2, NT, W>(s_x + x * TX::SIZE, a.aux[x] + (long)b * g.S, o0, o1, o2, g, 1.0f);
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int q = 0; q < QPT; ++q) {
+    const int row = (threadIdx.x / QR) * QPT + q;
+    const int l2 = W * owned_quad<QR, TG::S1, W>(), l1 = row % TG::T1, l0 = row / TG::T1;
+    const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+    if (i0 < g.N0 && i1 < g.N1 && i2 < g.N2) {
+      const long goff = ((long)i0 * g.N1 + i1) * g.N2 + i2;
+      acc.i0 = i0; acc.i1 = i1;
+      acc.ldsg = s_g + TG::at(l0, l1, l2);
+      acc.ldsgt = s_gt + TGT::at(l0, l1, l2);
+      acc.ldsa = s_a + TA::at(l0, l1, l2);
+      acc.ldsx = s_x + TX::at(l0, l1, l2);
+      if (!GT_ON) {
+#pragma unroll
+        for (int s = 0; s < NG; ++s) {
+          if (s == P::GTLO) continue;
+#pragma unroll
+          for (int k = 0; k < P::NE; ++k) {
+            const float cfk = cf[s][k];
+            fv v = vec_zero<W>();
+            if (cfk != 0.0f) v = *reinterpret_cast<const fv*>(rp[k] + (long)(tr0 + s - P::GTLO) * g.S + goff) * cfk;
+            acc.gc[s][k] = v;
+          }
+        }
+      }
+      fv out[P::NF];
+#pragma unroll
+      for (int px = 0; px < W; ++px) {
+        acc.px = px; acc.i2 = i2 + px;
+        float gr[P::NF];
+        P::adjoint(acc, gr);
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) out[f][px] = gr[f];
+      }
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f) *reinterpret_cast<fv*>(a.g[f] + frame + goff) = out[f];
+    }
   }
 }
 
