@@ -643,6 +643,26 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   }
 }
 
+// whole-tile staging helpers of the per-frame kernels (synchronous: fetch, scale, store)
+template <class TL, bool P0, bool P1, bool P2, int NT, int W>
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int o0, int o1, int o2, const Geom& g, float scale) {
+  using fv = typename VecOf<W>::type;
+  StagerQ<TL, P0, P1, P2, NT, W> st;
+  st.init(o0, o1, o2, g);
+  fv v[StagerQ<TL, P0, P1, P2, NT, W>::EPT];
+  st.fetch(v, src);
+#pragma unroll
+  for (int j = 0; j < StagerQ<TL, P0, P1, P2, NT, W>::EPT; ++j) v[j] = v[j] * scale;
+  st.store(v, tile);
+}
+
+template <class TL, int NT, int W>
+__device__ __forceinline__ void zero_tile_q(float* tile) {
+  using fv = typename VecOf<W>::type;
+  static_assert(TL::SIZE % W == 0, "tile size");
+  for (int i = threadIdx.x; i < TL::SIZE / W; i += NT) *reinterpret_cast<fv*>(tile + W * i) = vec_zero<W>();
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward, one residual frame per workgroup, quads: for PDEs whose time ring of halo tiles does not fit LDS
 // (3-D halos).  The frame's tile + halo is staged in LDS; the neighbouring frames are staged with the (smaller)
@@ -852,25 +872,6 @@ struct StoredAdjAccQ : SiteBase<P> {
     return v[e];
   }
 };
-
-template <class TL, bool P0, bool P1, bool P2, int NT, int W>
-__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int o0, int o1, int o2, const Geom& g, float scale) {
-  using fv = typename VecOf<W>::type;
-  StagerQ<TL, P0, P1, P2, NT, W> st;
-  st.init(o0, o1, o2, g);
-  fv v[StagerQ<TL, P0, P1, P2, NT, W>::EPT];
-  st.fetch(v, src);
-#pragma unroll
-  for (int j = 0; j < StagerQ<TL, P0, P1, P2, NT, W>::EPT; ++j) v[j] = v[j] * scale;
-  st.store(v, tile);
-}
-
-template <class TL, int NT, int W>
-__device__ __forceinline__ void zero_tile_q(float* tile) {
-  using fv = typename VecOf<W>::type;
-  static_assert(TL::SIZE % W == 0, "tile size");
-  for (int i = threadIdx.x; i < TL::SIZE / W; i += NT) *reinterpret_cast<fv*>(tile + W * i) = vec_zero<W>();
-}
 
 template <class P, int W>
 __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(const Args a) {
