@@ -114,15 +114,30 @@ __device__ __forceinline__ int owned_quad() {
   const int qd = (col) >= 0 ? (col) / W : -((W - 1 - (col)) / W); \
   const int e = (col) - W * qd;
 
-template <class P, class TL, class TX, int NS, int W>
+// LDS image of the time ring: field f owns NS consecutive tile slots when the residuals read it at other frames,
+// else a single slot (it is only ever needed at the frame being evaluated).
+template <class P, int NS, bool COMPACT>
+struct RingLayout {
+  static constexpr int slots(int f) { return (!COMPACT || P::tuse(f)) ? NS : 1; }
+  static constexpr int base(int f) { return f == 0 ? 0 : base(f - 1) + slots(f - 1); }     // in tiles
+  static constexpr int TILES = COMPACT ? base(P::NF) : NS * P::NF;
+  // tile index of field f at ring position r (r = frame % NS); the plain layout is position-major
+  static __device__ __forceinline__ int tile(int f, int r) { return COMPACT ? base(f) + (slots(f) == 1 ? 0 : r) : r * P::NF + f; }
+  // the frame a single-slot field holds while the ring fields hold `frame` as their newest: THI behind it
+  static constexpr bool single(int f) { return COMPACT && !P::tuse(f); }
+};
+
+template <class P, class TL, class TX, int NS, int W, bool COMPACT = false>
 struct RingAccQ : SiteBase<P> {
   using fv = typename VecOf<W>::type;
-  const float* fr[NS];       // &slot_of(tau - TLO + i)[field 0][row][quad start]
+  using RL = RingLayout<P, NS, COMPACT>;
+  const float* site;         // &ring[tile 0][row][quad start]
+  int ring[NS];              // ring position of frame tau - TLO + i
   const float* ldsx;
   int px;                    // which of the lane's 4 points
   __device__ __forceinline__ float F(int f, int ot, int o0, int o1, int o2) const {
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
-    const fv v = *reinterpret_cast<const fv*>(fr[ot + P::TLO] + f * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + W * qd);
+    const fv v = *reinterpret_cast<const fv*>(site + RL::tile(f, ring[ot + P::TLO]) * TL::SIZE + o0 * TL::S0 + o1 * TL::S1 + W * qd);
     return v[e];
   }
   __device__ __forceinline__ float X(int x, int o0, int o1, int o2) const {
@@ -143,7 +158,7 @@ struct QuadCfg {
   using TL = Tile<P::QF0, P::QF1, P::QF2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), padw<W>(cmax(P::RH2, P::RT2))>;
   using TXF = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, padw<W>(P::XH2)>;
   static constexpr int NS = P::TLO + P::THI + 1;
-  static constexpr long FWD_BYTES = 4L * (NS * P::NF * TL::SIZE + (P::NA ? P::NA * TXF::SIZE : 0));
+  static constexpr long FWD_BYTES = 4L * (RingLayout<P, NS, true>::TILES * TL::SIZE + (P::NA ? P::NA * TXF::SIZE : 0));
   static constexpr bool FWD_OK = FWD_BYTES <= 64 * 1024 && P::QF2 % W == 0 && (P::QF0 * P::QF1 * (P::QF2 / W)) % NT == 0 &&
                                  NT % (P::QF2 / W) == 0 && NT <= 1024;
   // backward tiles
@@ -166,7 +181,7 @@ struct QuadCfg {
 // forward, marching, quads: workgroup = (sample, chunk of residual frames, tile)
 // ------------------------------------------------------------------------------------------------
 template <class P, int W, bool WRITE_R>
-__global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const Args a) {
+__global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kernel(const Args a) {
   using C = QuadCfg<P, W>;
   using fv = typename VecOf<W>::type;
   using TL = typename C::TL;
@@ -178,7 +193,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
   constexpr int QPT = (TL::T0 * TL::T1 * QR) / NT;      // quads (consecutive rows) per thread
   using ST = StagerQ<TL, P::PER0, P::PER1, P::PER2, NT, W>;
 
-  __shared__ __attribute__((aligned(16))) float s_f[NS * P::NF * TL::SIZE];
+  using RL = RingLayout<P, NS, true>;
+  __shared__ __attribute__((aligned(16))) float s_f[RL::TILES * TL::SIZE];
   __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
   __shared__ double s_red[(NT / 64) * P::NE];
 
@@ -201,9 +217,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
   for (int fr = ra - P::TLO; fr <= ra + P::THI; ++fr) {
 #pragma unroll
     for (int f = 0; f < P::NF; ++f) {
-      fv v[ST::EPT];
-      st.fetch(v, fb[f] + (long)fr * g.S);
-      st.store(v, s_f + ((fr % NS) * P::NF + f) * TL::SIZE);
+      if (!RL::single(f) || fr == ra) {      // single-slot fields hold the frame being evaluated only
+        fv v[ST::EPT];
+        st.fetch(v, fb[f] + (long)fr * g.S);
+        st.store(v, s_f + RL::tile(f, fr % NS) * TL::SIZE);
+      }
     }
   }
   if (AUX_ON) {
@@ -219,7 +237,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
   }
   __syncthreads();
 
-  RingAccQ<P, TL, TX, NS, W> acc;
+  RingAccQ<P, TL, TX, NS, W, true> acc;
   acc.template set_uniforms<true>(a.c, a.sp, b);
   acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
 
@@ -250,7 +268,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
     fv stage[P::NF][ST::EPT];
     if (more) {
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)fnew * g.S);
+      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)(RL::single(f) ? tau + 1 : fnew) * g.S);
     }
     float wk[P::NE];
 #pragma unroll
@@ -262,7 +280,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
     for (int q = 0; q < QPT; ++q) {
       acc.i0 = pi0[q]; acc.i1 = pi1[q];
 #pragma unroll
-      for (int i = 0; i < NS; ++i) acc.fr[i] = s_f + (((tau - P::TLO + i) % NS) * P::NF) * TL::SIZE + site[q];
+      for (int i = 0; i < NS; ++i) acc.ring[i] = (tau - P::TLO + i) % NS;
+      acc.site = s_f + site[q];
       acc.ldsx = s_x + tsite[q];
       float part[P::NE];
 #pragma unroll
@@ -304,7 +323,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT)) void fwd_march_q_kernel(const 
     if (more) {
       __syncthreads();
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % NS) * P::NF + f) * TL::SIZE);
+      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + RL::tile(f, fnew % NS) * TL::SIZE);
       __syncthreads();
     }
   }
@@ -527,7 +546,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
         {
           racc.i0 = r0[j]; racc.i1 = r1[j];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) racc.fr[i] = s_f + (((n + 2 + i) % 3) * P::NF) * TF::SIZE + rF[j];
+          for (int i = 0; i < 3; ++i) racc.ring[i] = (n + 2 + i) % 3;
+          racc.site = s_f + rF[j];
           racc.ldsx = s_x + rX[j];
 #pragma unroll
           for (int px = 0; px < W; ++px) {

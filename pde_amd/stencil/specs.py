@@ -47,6 +47,7 @@ class Spec:
     waves_per_simd_quad: int = 2
     quad_width_fwd: int = 4
     quad_width_bwd: int = 4
+    waves_per_simd_quad_fwd: int = 1    # forward quad kernel: compile for this many waves per SIMD (1 = no constraint)
     quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
 
     # derived
