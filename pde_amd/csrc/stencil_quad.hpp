@@ -214,15 +214,18 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
 #pragma unroll
   for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
 
-  for (int fr = ra - P::TLO; fr <= ra + P::THI; ++fr) {
+  {   // all first frames are fetched before any is stored: one memory round trip instead of one per frame
+    fv v0[NS][P::NF][ST::EPT];
 #pragma unroll
-    for (int f = 0; f < P::NF; ++f) {
-      if (!RL::single(f) || fr == ra) {      // single-slot fields hold the frame being evaluated only
-        fv v[ST::EPT];
-        st.fetch(v, fb[f] + (long)fr * g.S);
-        st.store(v, s_f + RL::tile(f, fr % NS) * TL::SIZE);
-      }
-    }
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f)
+        if (!RL::single(f) || i == P::TLO) st.fetch(v0[i][f], fb[f] + (long)(ra - P::TLO + i) * g.S);   // single-slot fields: frame ra only
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int f = 0; f < P::NF; ++f)
+        if (!RL::single(f) || i == P::TLO) st.store(v0[i][f], s_f + RL::tile(f, (ra - P::TLO + i) % NS) * TL::SIZE);
   }
   if (AUX_ON) {
     using SX = StagerQ<TX, P::PER0, P::PER1, P::PER2, NT, W>;
@@ -414,6 +417,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
 
   const int na = max(qa - 1, 1), nb = min(qb, g.T - 2);
   const int n0 = qa - 1;
+  // one frame at a time: fetching all three at once measured slower here (the workgroups of a CU fall into step)
   for (int fr = max(n0 - 1, 0); fr <= min(n0 + 1, g.T - 1); ++fr) {
 #pragma unroll
     for (int f = 0; f < P::NF; ++f) {

@@ -48,6 +48,9 @@ class HipBackend:
     """Launches the gfx950 kernels. Tensors must live on a HIP device."""
 
     name = "hip"
+    # Optional instrumentation: when set to a list, every backward launch appends a (start, end) pair of events recorded
+    # on the launch stream right around the C call, so a benchmark can time the adjoint kernel alone.
+    backward_events = None
 
     @staticmethod
     def _stream(t: torch.Tensor):
@@ -92,10 +95,17 @@ class HipBackend:
         rptr = _lib.ptr_array(resid, len(resid)) if resid is not None else None
         uptr = _lib.ptr_array(upstream, len(s.eqs) + 1) if upstream is not None else None
         gs = C.c_void_p(upstream_sums.data_ptr()) if upstream_sums is not None else None
+        ev = None
+        if self.backward_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         with torch.cuda.device(f0.device):
             st = L.pde_amd_residual_backward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                              _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), uptr, gs,
                                              rptr, _lib.ptr_array(grads, len(grads)), None, 0, self._stream(f0))
+        if ev is not None:
+            ev[1].record()
+            self.backward_events.append(ev)
         _lib.check(st, f"residual_backward[{prob.spec}]")
         return grads
 
