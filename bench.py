@@ -137,6 +137,8 @@ def main():
         step()
     kernel_events = []
     PF.get_backend().backward_events = kernel_events      # (start, end) events right around each adjoint launch
+    PF.get_backend().backward_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                            for _ in range(args.steps + 2)]
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()

@@ -9,6 +9,7 @@ Everything runs on the current torch HIP stream.  There is no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -28,6 +29,13 @@ class StencilProblem:
     hi: Tuple[int, int, int] = (0, 0, 0)
 
     def c_struct(self, shape: Sequence[int]) -> "_lib.Problem":
+        key = tuple(shape)
+        cache = self.__dict__.setdefault("_cstructs", {})
+        if key not in cache:
+            cache[key] = self._c_struct(shape)
+        return cache[key]
+
+    def _c_struct(self, shape: Sequence[int]) -> "_lib.Problem":
         s = SPECS[self.spec]
         nd = s.ndim
         if len(shape) != 2 + nd:
@@ -51,10 +59,28 @@ class HipBackend:
     # Optional instrumentation: when set to a list, every backward launch appends a (start, end) pair of events recorded
     # on the launch stream right around the C call, so a benchmark can time the adjoint kernel alone.
     backward_events = None
+    backward_event_pool = None       # optional list of pre-created (start, end) event pairs to draw from
 
     @staticmethod
     def _stream(t: torch.Tensor):
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    _ws = {}
+
+    def _workspace(self, device, nbytes: int) -> torch.Tensor:
+        """Scratch for partial sums, reused across calls: every use is ordered on the stream it was launched on, and a
+        buffer is kept per (device, stream)."""
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    @staticmethod
+    def _on(device):
+        """Context that makes `device` current for the launch; free when it already is."""
+        return contextlib.nullcontext() if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
     def can_recompute(self, spec: str) -> bool:
         return bool(_lib.pde_info(spec).can_recompute)
@@ -72,13 +98,13 @@ class HipBackend:
         sums = torch.empty((B, ne), dtype=torch.float64, device=f0.device)
         totals = torch.empty((ne + 1,), dtype=torch.float32, device=f0.device)
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f0.device)
+        ws = self._workspace(f0.device, ws_bytes)
         resid = None
         rptr = None
         if store_residuals:
             resid = [torch.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float32, device=f0.device) for _ in range(ne)]
             rptr = _lib.ptr_array(resid, ne)
-        with torch.cuda.device(f0.device):
+        with self._on(f0.device):
             st = L.pde_amd_residual_forward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                             _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()),
                                             C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), rptr,
@@ -97,9 +123,10 @@ class HipBackend:
         gs = C.c_void_p(upstream_sums.data_ptr()) if upstream_sums is not None else None
         ev = None
         if self.backward_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = self.backward_event_pool.pop() if self.backward_event_pool else (
+                torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        with torch.cuda.device(f0.device):
+        with self._on(f0.device):
             st = L.pde_amd_residual_backward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                              _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), uptr, gs,
                                              rptr, _lib.ptr_array(grads, len(grads)), None, 0, self._stream(f0))

@@ -55,6 +55,13 @@ class StencilPDELoss(nn.Module):
 
     # -- helpers ----------------------------------------------------------------------------------
     def _problem(self, spatial) -> StencilProblem:
+        key = ("problem", tuple(spatial), tuple(sorted((k, v if isinstance(v, (int, float, str, bool)) else repr(v)) for k, v in self._params().items())))
+        hit = self._wt_cache.get(key)
+        if hit is None:
+            hit = self._wt_cache[key] = self._build_problem(spatial)
+        return hit
+
+    def _build_problem(self, spatial) -> StencilProblem:
         spec = SPECS[self.SPEC]
         p = self._params()
         consts = [fn(p) for _, fn in spec.consts]
