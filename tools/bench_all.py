@@ -27,9 +27,9 @@ def timeit(fn, n=15, warm=3):
 # (class, ctor kwargs, field shape, per-sample kwargs builder)
 U = lambda B, lo, hi: lo + (hi - lo) * torch.rand(B, device=dev)
 CASES = [
-    ("C1 Burgers1D", "Burgers1DPDELoss", dict(nx=256, dt=0.01), (20, 9, 256), lambda B: dict(nu=U(B, 0.005, 0.1))),
-    ("Burgers1D large", "Burgers1DPDELoss", dict(nx=4096, dt=0.01), (512, 17, 4096), lambda B: dict(nu=U(B, 0.005, 0.1))),
-    ("Heat1D", "Heat1DPDELoss", dict(nx=4096, dt=0.01), (512, 17, 4096), lambda B: dict(alpha=U(B, 0.01, 0.1))),
+    ("C1 Burgers1D", "Burgers1DPDELoss", dict(dt=0.01), (20, 9, 256), lambda B: dict(nu=U(B, 0.005, 0.1))),
+    ("Burgers1D large", "Burgers1DPDELoss", dict(dx=2 * 3.141592653589793 / 4096, dt=0.01), (512, 17, 4096), lambda B: dict(nu=U(B, 0.005, 0.1))),
+    ("Heat1D", "Heat1DPDELoss", dict(dx=2 * 3.141592653589793 / 4096, dt=0.01), (512, 17, 4096), lambda B: dict(alpha=U(B, 0.01, 0.1))),
     ("KdV1D", "KdV1DPDELoss", dict(), (512, 17, 4096), lambda B: {}),
     ("C2 TaylorGreen2D", "TaylorGreen2DPDELoss", dict(nx=256, ny=256, dt=0.01), (16, 16, 256, 256), lambda B: dict(nu=U(B, 0.01, 0.1))),
     ("C3 GrayScott fd4 (8/GPU)", "GrayScottPDELoss", dict(laplacian="fd4"), (8, 9, 128, 128), lambda B: {}),
@@ -53,6 +53,10 @@ CASES = [
 ]
 
 
+def pk_names(params):
+    return set(params(1).keys())
+
+
 def main():
     rows = []
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -65,9 +69,8 @@ def main():
         except TypeError as e:
             print(f"{tag:28s} ctor failed: {e}")
             continue
-        nf = len(SPECS[mod.SPEC].fields)
         fwd_params = inspect.signature(mod.forward).parameters
-        names = list(fwd_params)[:nf]
+        nf = sum(1 for q in fwd_params.values() if q.default is inspect.Parameter.empty and q.name not in pk_names(params))
         gen = torch.Generator(device=dev).manual_seed(1)
         fields = [(1.0 + 0.1 * torch.randn(shape, device=dev, generator=gen)).requires_grad_(True) for _ in range(nf)]
         pk = params(shape[0])
