@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const GatherArgs a, float*
       v[k] = r;
       if (++c == C) { c = 0; ++pt; }
     }
-    if (VEC == 4) *reinterpret_cast<f4*>(dst + i) = f4{v[0], v[1], v[2], v[3]};
+    if (VEC == 4) __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(dst + i));      // streamed once, never re-read here
     else dst[i] = v[0];
   }
 }

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(P::NT) void bwd_stored_kernel(const Args a) {
       float gr[P::NF];
       P::adjoint(acc, gr);
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) a.g[f][frame + acc.goff] = gr[f];
+      for (int f = 0; f < P::NF; ++f) __builtin_nontemporal_store(gr[f], &a.g[f][frame + acc.goff]);   // written once, never re-read here
     }
   }
 }
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(P::NTM, P::WPS) void bwd_march_kernel(const Args a)
         if (inside[p]) {
           const long o = (long)(n - 1) * g.S + goff[p];
 #pragma unroll
-          for (int f = 0; f < P::NF; ++f) a.g[f][(long)b * g.T * g.S + o] = Sprev[p][f] + gt[f];
+          for (int f = 0; f < P::NF; ++f) __builtin_nontemporal_store(Sprev[p][f] + gt[f], &a.g[f][(long)b * g.T * g.S + o]);
         }
       }
       float gs[P::NF];

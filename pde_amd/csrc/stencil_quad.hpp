@@ -651,7 +651,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
         if (inside[q]) {
           const long o = (long)b * g.T * g.S + (long)(n - 1) * g.S + goff[q];
 #pragma unroll
-          for (int f = 0; f < P::NF; ++f) *reinterpret_cast<fv*>(a.g[f] + o) = out[q][f];
+          for (int f = 0; f < P::NF; ++f) __builtin_nontemporal_store(out[q][f], reinterpret_cast<fv*>(a.g[f] + o));   // streamed: keeps the fields in cache
         }
       }
     }
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
         for (int f = 0; f < P::NF; ++f) out[f][px] = gr[f];
       }
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) *reinterpret_cast<fv*>(a.g[f] + frame + goff) = out[f];
+      for (int f = 0; f < P::NF; ++f) __builtin_nontemporal_store(out[f], reinterpret_cast<fv*>(a.g[f] + frame + goff));
     }
   }
 }
