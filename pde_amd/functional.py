@@ -60,6 +60,8 @@ class HipBackend:
     # on the launch stream right around the C call, so a benchmark can time the adjoint kernel alone.
     backward_events = None
     backward_event_pool = None       # optional list of pre-created (start, end) event pairs to draw from
+    forward_events = None            # same for the forward launches (residual kernel + the two tiny reductions)
+    forward_event_pool = None
 
     @staticmethod
     def _stream(t: torch.Tensor):
@@ -104,11 +106,19 @@ class HipBackend:
         if store_residuals:
             resid = [torch.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float32, device=f0.device) for _ in range(ne)]
             rptr = _lib.ptr_array(resid, ne)
+        ev = None
+        if self.forward_events is not None:
+            ev = self.forward_event_pool.pop() if self.forward_event_pool else (
+                torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         with self._on(f0.device):
             st = L.pde_amd_residual_forward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                             _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()),
                                             C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), rptr,
                                             C.c_void_p(ws.data_ptr()), ws_bytes, self._stream(f0))
+        if ev is not None:
+            ev[1].record()
+            self.forward_events.append(ev)
         _lib.check(st, f"residual_forward[{prob.spec}]")
         return totals, sums, resid
 
