@@ -102,7 +102,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("PDE_AMD_BENCH_FORCE_DIST") == "1"     # the latter: rehearse the RCCL path with one rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -145,7 +145,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to query events
                 g_total, g_losses = loss_step()
             graph.replay()
             torch.cuda.synchronize()
