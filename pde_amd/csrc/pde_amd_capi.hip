@@ -30,6 +30,12 @@ static inline bool aligned_vec(const float* const* p) {
     if (reinterpret_cast<uintptr_t>(p[i]) & (4 * W - 1)) return false;
   return true;
 }
+// The vector kernels address a frame with 32-bit byte offsets (bit 31 is a flag) and a sample's frames through a
+// buffer descriptor of at most 4 GiB; larger problems take the dword kernels, which use 64-bit addresses.
+static inline bool quad_addressable(const pde_amd_problem* p) {
+  const long S = (long)p->n[0] * p->n[1] * p->n[2];
+  return S < (1L << 29) && (long)p->frames * S < (1L << 30);
+}
 static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 // Frames per marching workgroup: whole clips when samples x tiles already fill the chip, shorter chunks
@@ -118,7 +124,7 @@ struct Ops {
       }
       bool launched = false;
       if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
-        if (p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
+        if (quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
             (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
           fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
           const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
@@ -130,7 +136,7 @@ struct Ops {
         }
       }
       if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK) {
-        if (!launched && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
+        if (!launched && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
             (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
           fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
           items = tr * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
@@ -145,7 +151,7 @@ struct Ops {
         if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
         hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
       }
-    } else if (QuadCfg<P, P::QWF>::FWD_OK && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
+    } else if (QuadCfg<P, P::QWF>::FWD_OK && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
                (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
       if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
         fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
@@ -155,7 +161,7 @@ struct Ops {
         if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
         hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF, false>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
       }
-    } else if (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
+    } else if (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
                (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
       if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK) {
         fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
@@ -215,7 +221,7 @@ struct Ops {
       }
       bool launched = false;
       if constexpr (StoredCfg<P, P::QWB>::OK) {
-        if (p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) && aligned_vec<P::NF, P::QWB>(grads) &&
+        if (quad_addressable(p) && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) && aligned_vec<P::NF, P::QWB>(grads) &&
             aligned_vec<P::NE, P::QWB>(resid_in) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
           fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);
           const long nwgq = (long)p->batch * p->frames * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
@@ -229,7 +235,7 @@ struct Ops {
         if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
         hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
       }
-    } else if (QuadCfg<P, P::QWB>::BWD_OK && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) &&
+    } else if (QuadCfg<P, P::QWB>::BWD_OK && quad_addressable(p) && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) &&
                aligned_vec<P::NF, P::QWB>(grads) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
       if constexpr (QuadCfg<P, P::QWB>::BWD_OK) {
         fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);
@@ -242,7 +248,7 @@ struct Ops {
 #else
         constexpr int dyn_lds = 0;
 #endif
-        hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NT), dyn_lds, stream, a);
+        hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
       }
     } else {
       if constexpr (BwdMarchFits<P>::value) {
@@ -271,7 +277,11 @@ struct Ops {
   }
 };
 
+#ifdef PDE_AMD_DIAG_ONLY      // diagnostic builds (-DPDE_AMD_DIAG_ONLY=Pde_tg2d): every slot runs that PDE's kernels; compiles in seconds
+#define PDE_AMD_VT(P) Ops<PDE_AMD_DIAG_ONLY>::vtable(),
+#else
 #define PDE_AMD_VT(P) Ops<P>::vtable(),
+#endif
 static const PdeVTable kTable[] = {PDE_AMD_FOR_EACH_PDE(PDE_AMD_VT)};
 static constexpr int kNumPdes = sizeof(kTable) / sizeof(kTable[0]);
 

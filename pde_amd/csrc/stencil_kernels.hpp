@@ -119,11 +119,13 @@ template <class P>
 struct SiteBase {
   float cv[MAXC];            // constants (only the first P::NC are ever set or read)
   float spv[MAXSP];          // per-sample parameters of this sample
+  float uv[P::NU > 0 ? P::NU : 1];   // hoisted uniform subexpressions (P::uniforms); entries an accessor never reads are dead code
   int i0, i1, i2, N0, N1, N2;
   bool vg = false;           // set_uniforms<true>: uniform values live in vector registers
   __device__ __forceinline__ float c(int i) const { return cv[i]; }
   __device__ __forceinline__ float k(float x) const { return vg ? to_vgpr(x) : x; }   // numeric literal
   __device__ __forceinline__ float sp(int i) const { return spv[i]; }
+  __device__ __forceinline__ float u(int i) const { return uv[i]; }
   // VG: keep the uniform values in vector registers.  A VALU instruction with a scalar-register operand
   // issues at half the rate of one whose operands are all vector registers (measured: 4 vs 2-2.5 cycles per
   // wave64 instruction), and these values are operands of most of the generated arithmetic.
@@ -134,6 +136,7 @@ struct SiteBase {
     for (int i = 0; i < P::NC; ++i) cv[i] = VG ? to_vgpr(c[i]) : c[i];
 #pragma unroll
     for (int i = 0; i < P::NSP; ++i) spv[i] = VG ? to_vgpr(ldc(spp[i], b)) : ldc(spp[i], b);
+    P::uniforms(*this, uv);
   }
   __device__ __forceinline__ bool at(int axis, int k) const { return (axis == 0 ? i0 : axis == 1 ? i1 : i2) == k; }
   __device__ __forceinline__ bool ath(int axis, int k) const {

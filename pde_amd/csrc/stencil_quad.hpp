@@ -45,6 +45,36 @@ __device__ __forceinline__ int wrap_quad(int c, int N, bool& ok) {
   return c;
 }
 
+// Global memory through buffer instructions: a scalar descriptor (base pointer, size) plus a scalar byte offset
+// (the frame) plus one 32-bit lane offset.  Plain pointer arithmetic makes the compiler keep a 64-bit address per
+// lane and field, two registers each, because it folds the loop-invariant part of "base + frame + lane" into the
+// lane term; the buffer form keeps everything uniform in scalar registers.  `bytes` (< 4 GiB, checked by the
+// host) bounds the lane offset; reads past it return zero and writes are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+template <int W> struct BufIO;
+template <> struct BufIO<2> {
+  typedef unsigned uv __attribute__((ext_vector_type(2)));
+  typedef VecOf<2>::type fv;
+  static __device__ __forceinline__ fv load(__amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
+    return __builtin_bit_cast(fv, __builtin_amdgcn_raw_buffer_load_b64(r, lane, frame, 0));
+  }
+  static __device__ __forceinline__ void store_nt(fv v, __amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uv, v), r, lane, frame, 2);
+  }
+};
+template <> struct BufIO<4> {
+  typedef unsigned uv __attribute__((ext_vector_type(4)));
+  typedef VecOf<4>::type fv;
+  static __device__ __forceinline__ fv load(__amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
+    return __builtin_bit_cast(fv, __builtin_amdgcn_raw_buffer_load_b128(r, lane, frame, 0));
+  }
+  static __device__ __forceinline__ void store_nt(fv v, __amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uv, v), r, lane, frame, 2);
+  }
+};
+
 // Per-thread vector elements of one halo tile; offsets are computed once per workgroup.
 template <class TL, bool P0, bool P1, bool P2, int NT, int W>
 struct StagerQ {
@@ -53,7 +83,11 @@ struct StagerQ {
   static constexpr int QROW = TL::D2 / W;
   static constexpr int NQ = TL::D0 * TL::D1 * QROW;
   static constexpr int EPT = (NQ + NT - 1) / NT;
-  int off[EPT];
+  // Byte offset of each element inside a frame, as 32 bits (the host checks that a frame is smaller than 2 GiB):
+  // with a wave-uniform frame pointer the load then takes "scalar base + 32-bit lane offset" and no 64-bit
+  // per-lane address has to be kept.  Bit 31 marks an element that lies outside a non-periodic domain.
+  unsigned off[EPT];
+  static constexpr unsigned OUTSIDE = 0x80000000u;
   bool plain[EPT];       // wave-uniform: no lane of the wave has to substitute zeros for element j
   __device__ __forceinline__ void init(int o0, int o1, int o2, const Geom& g) {
 #pragma unroll
@@ -64,14 +98,19 @@ struct StagerQ {
       const int c0 = wrap_coord<P0>(o0 + l0 - TL::H0, g.N0, ok);
       const int c1 = wrap_coord<P1>(o1 + l1 - TL::H1, g.N1, ok);
       const int c2 = wrap_quad<P2, W>(o2 + W * lq - TL::H2, g.N2, ok);
-      off[j] = ok ? (c0 * g.N1 + c1) * g.N2 + c2 : -1;
+      off[j] = ok ? 4u * (unsigned)((c0 * g.N1 + c1) * g.N2 + c2) : OUTSIDE;
       plain[j] = wave_all(ok || i >= NQ);
     }
   }
   __device__ __forceinline__ void fetch(fv (&v)[EPT], const float* __restrict__ frame) const {
-#pragma unroll
     // always a valid address, and no use of the result here: the loads stay in flight until store()
-    for (int j = 0; j < EPT; ++j) v[j] = *reinterpret_cast<const fv*>(frame + max(off[j], 0));
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] = *reinterpret_cast<const fv*>(reinterpret_cast<const char*>(frame) + (off[j] & ~OUTSIDE));
+  }
+  // the same through a buffer descriptor of the sample's frames; `frame` is the byte offset of the frame
+  __device__ __forceinline__ void fetch(fv (&v)[EPT], __amdgpu_buffer_rsrc_t r, unsigned frame) const {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] = BufIO<W>::load(r, off[j] & ~OUTSIDE, frame);
   }
   // An unconditional use of the fetched registers.  The compiler places its wait for a load at the first
   // use; when every use sits under a branch, the path around the branch leaves the load "pending" in the
@@ -90,7 +129,7 @@ struct StagerQ {
       if (EPT * NT == NQ || i < NQ) {
         // wall-side quads read 0; the select is skipped (a real branch) where no lane of the wave needs it
         if (plain[j]) *reinterpret_cast<fv*>(tile + W * i) = v[j];
-        else *reinterpret_cast<fv*>(tile + W * i) = off[j] >= 0 ? v[j] : z;
+        else *reinterpret_cast<fv*>(tile + W * i) = (off[j] & OUTSIDE) ? z : v[j];
       }
     }
   }
@@ -153,6 +192,7 @@ struct QuadCfg {
   static_assert(W == 2 || W == 4, "lane width");
   // the same tile is covered by 4/W times the lanes
   static constexpr int NT = P::NTQ * 4 / W;
+  static constexpr int NTB = P::NTQB * 4 / W;  // the adjoint may use another workgroup size than the forward kernel
   static constexpr int WPS = P::WPSQ;          // waves per SIMD the adjoint is compiled for
   // forward tile
   using TL = Tile<P::QF0, P::QF1, P::QF2, cmax(P::RH0, P::RT0), cmax(P::RH1, P::RT1), padw<W>(cmax(P::RH2, P::RT2))>;
@@ -174,7 +214,7 @@ struct QuadCfg {
   using TXB = Tile<P::QB0, P::QB1, P::QB2, cmax(P::XH0, P::GH0), cmax(P::XH1, P::GH1), padw<W>(cmax(P::XH2, padw<W>(P::GH2)))>;
   static constexpr long BWD_BYTES = 4L * (3 * P::NF * TF::SIZE + 2 * LDS_PAD + P::NE * TG::SIZE + (P::NA ? P::NA * TXB::SIZE : 0));
   static constexpr bool BWD_OK = MarchOK<P>::value && BWD_BYTES <= LDS_BUDGET && P::QB2 % W == 0 &&
-                                 (P::QB0 * P::QB1 * (P::QB2 / W)) % NT == 0 && NT % (P::QB2 / W) == 0 && NT <= 1024;
+                                 (P::QB0 * P::QB1 * (P::QB2 / W)) % NTB == 0 && NTB % (P::QB2 / W) == 0 && NTB <= 1024;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -213,6 +253,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
   const float* fb[P::NF];
 #pragma unroll
   for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
+  // buffer descriptors of this sample's frames; a frame is addressed by its byte offset
+  const unsigned sample_bytes = 4u * (unsigned)(g.T * g.S), frame_bytes = 4u * (unsigned)g.S;
+  __amdgpu_buffer_rsrc_t fbuf[P::NF];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) fbuf[f] = buffer_of(fb[f], sample_bytes);
 
   {   // all first frames are fetched before any is stored: one memory round trip instead of one per frame
     fv v0[NS][P::NF][ST::EPT];
@@ -220,7 +265,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
     for (int i = 0; i < NS; ++i)
 #pragma unroll
       for (int f = 0; f < P::NF; ++f)
-        if (!RL::single(f) || i == P::TLO) st.fetch(v0[i][f], fb[f] + (long)(ra - P::TLO + i) * g.S);   // single-slot fields: frame ra only
+        if (!RL::single(f) || i == P::TLO) st.fetch(v0[i][f], fbuf[f], (unsigned)(ra - P::TLO + i) * frame_bytes);   // single-slot fields: frame ra only
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -271,7 +316,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
     fv stage[P::NF][ST::EPT];
     if (more) {
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fb[f] + (long)(RL::single(f) ? tau + 1 : fnew) * g.S);
+      for (int f = 0; f < P::NF; ++f) st.fetch(stage[f], fbuf[f], (unsigned)(RL::single(f) ? tau + 1 : fnew) * frame_bytes);
     }
     float wk[P::NE];
 #pragma unroll
@@ -377,19 +422,36 @@ struct MarchAdjAccQ : SiteBase<P> {
 #endif
 
 template <class P, int W>
-__global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd_march_q_kernel(const Args a) {
+__global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bwd_march_q_kernel(const Args a) {
   using C = QuadCfg<P, W>;
   using fv = typename VecOf<W>::type;
   using TF = typename C::TF;
   using TG = typename C::TG;
   using TX = typename C::TXB;
   constexpr bool AUX_ON = P::NA > 0;
-  constexpr int NT = C::NT;
+  constexpr int NT = C::NTB;
   constexpr int QR = TG::T2 / W;                         // quads per tile row
   constexpr int QPT = (TG::T0 * TG::T1 * QR) / NT;       // output quads per thread
   constexpr int GQR = TG::D2 / W;                        // quads per region row
   constexpr int NRQ = TG::D0 * TG::D1 * GQR;             // region quads
   constexpr int RPT = (NRQ + NT - 1) / NT;
+  // The last round of the residual stage covers what is left of the region after RPT-1 full rounds.  When that
+  // is at most half a workgroup, the lower and the upper half of the workgroup take it on alternate steps, so
+  // the extra work lands on all SIMDs in turn instead of always on the ones that run the first waves.
+  // Other-frame adjoint terms that read no fields are linear in the scaled residuals with uniform coefficients:
+  // the earlier frame's share is added as soon as it is known, and only one past frame of residuals is kept.
+  constexpr bool SPLIT_T = P::TIME_AF == 0;
+#ifdef PDE_AMD_ABL_NO_TIME      // diagnostic: drop the other-frame terms (wrong gradients, two fewer registers sets)
+  constexpr bool NO_TIME = true;
+#else
+  constexpr bool NO_TIME = false;
+#endif
+#ifdef PDE_AMD_VGU
+  constexpr bool VGU = PDE_AMD_VGU;
+#else
+  constexpr bool VGU = true;
+#endif
+  constexpr bool ALT = RPT >= 2 && NT % 128 == 0 && NRQ - (RPT - 1) * NT <= NT / 2;
   using ST = StagerQ<TF, P::PER0, P::PER1, P::PER2, NT, W>;
   static_assert(C::BWD_OK, "PDE not eligible for the quad marching adjoint");
 
@@ -412,6 +474,14 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   const float* fb[P::NF];
 #pragma unroll
   for (int f = 0; f < P::NF; ++f) fb[f] = a.f[f] + (long)b * g.T * g.S;
+  // buffer descriptors of this sample's frames (fields) and gradient frames; frames are addressed by byte offset
+  const unsigned sample_bytes = 4u * (unsigned)(g.T * g.S), frame_bytes = 4u * (unsigned)g.S;
+  __amdgpu_buffer_rsrc_t fbuf[P::NF], gbuf[P::NF];
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) {
+    fbuf[f] = buffer_of(fb[f], sample_bytes);
+    gbuf[f] = buffer_of(a.g[f] + (long)b * g.T * g.S, sample_bytes);
+  }
   float up[P::NE];
   upstream_of<P>(a, b, up);
 
@@ -422,7 +492,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
 #pragma unroll
     for (int f = 0; f < P::NF; ++f) {
       fv v[ST::EPT];
-      st.fetch(v, fb[f] + (long)fr * g.S);
+      st.fetch(v, fbuf[f], (unsigned)fr * frame_bytes);
       st.store(v, s_f + ((fr % 3) * P::NF + f) * TF::SIZE);
     }
   }
@@ -443,7 +513,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   bool rrow[RPT], rfull[RPT];      // rfull: wave-uniform, every point of every active lane's quad lies on the lattice
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int iraw = threadIdx.x + j * NT;
+    const int iraw = (ALT && j == RPT - 1 ? (int)threadIdx.x % (NT / 2) : (int)threadIdx.x) + j * NT;
     const int i = iraw < NRQ ? iraw : 0;
     const int lq = i % GQR, rr = i / GQR;
     const int l2 = W * lq - TG::H2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
@@ -458,7 +528,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
     rF[j] = TF::at(l0, l1, l2);
     rX[j] = TX::at(l0, l1, l2);
   }
-  int sF[QPT], sG[QPT], sX[QPT], goff[QPT], pi0[QPT], pi1[QPT], pi2[QPT];
+  int sF[QPT], sG[QPT], sX[QPT], pi0[QPT], pi1[QPT], pi2[QPT];
+  unsigned goff[QPT];      // byte offset inside a frame (32 bits: scalar base + lane offset addressing, see StagerQ)
   bool inside[QPT];
 #pragma unroll
   for (int q = 0; q < QPT; ++q) {
@@ -467,17 +538,19 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
     pi0[q] = o0 + l0; pi1[q] = o1 + l1; pi2[q] = o2 + l2;
     inside[q] = pi0[q] < g.N0 && pi1[q] < g.N1 && pi2[q] < g.N2;
     sF[q] = TF::at(l0, l1, l2); sG[q] = TG::at(l0, l1, l2); sX[q] = TX::at(l0, l1, l2);
-    goff[q] = (pi0[q] * g.N1 + pi1[q]) * g.N2 + pi2[q];
+    goff[q] = 4u * (unsigned)((pi0[q] * g.N1 + pi1[q]) * g.N2 + pi2[q]);
   }
 
   RingAccQ<P, TF, TX, 3, W> racc;
-  racc.template set_uniforms<true>(a.c, a.sp, b);
+  racc.template set_uniforms<VGU>(a.c, a.sp, b);
   MarchAdjAccQ<P, TF, TG, TX, W> aacc;
-  aacc.vg = true;
+  aacc.vg = VGU;
 #pragma unroll
   for (int i = 0; i < P::NC; ++i) aacc.cv[i] = racc.cv[i];
 #pragma unroll
   for (int i = 0; i < P::NSP; ++i) aacc.spv[i] = racc.spv[i];
+#pragma unroll
+  for (int i = 0; i < P::NU; ++i) aacc.uv[i] = racc.uv[i];
   racc.N0 = aacc.N0 = g.N0; racc.N1 = aacc.N1 = g.N1; racc.N2 = aacc.N2 = g.N2;
 
   float Sprev[QPT][W][P::NF];
@@ -514,17 +587,17 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   fv stage_a[P::NF][ST::EPT], stage_b[P::NF][ST::EPT];
   if (DEEP) {
 #pragma unroll
-    for (int f = 0; f < P::NF; ++f) st.fetch(stage_b[f], fb[f] + (long)min(n0 + 2, g.T - 1) * g.S);
+    for (int f = 0; f < P::NF; ++f) st.fetch(stage_b[f], fbuf[f], (unsigned)min(n0 + 2, g.T - 1) * frame_bytes);
   }
 
-  auto step = [&](const int n, fv (&stage_new)[P::NF][ST::EPT], fv (&stage)[P::NF][ST::EPT]) __attribute__((always_inline)) {
+  auto step = [&](const int n, const int half, fv (&stage_new)[P::NF][ST::EPT], fv (&stage)[P::NF][ST::EPT]) __attribute__((always_inline)) {
     const int fnew = n + 2;
     const bool more = n < qb && fnew < g.T;
     PDE_AMD_STAMP(0);
 #pragma unroll
     for (int f = 0; f < P::NF; ++f) {
-      if (DEEP) st.fetch(stage_new[f], fb[f] + (long)min(n + 3, g.T - 1) * g.S);
-      else st.fetch(stage[f], fb[f] + (long)min(n + 2, g.T - 1) * g.S);
+      if (DEEP) st.fetch(stage_new[f], fbuf[f], (unsigned)min(n + 3, g.T - 1) * frame_bytes);
+      else st.fetch(stage[f], fbuf[f], (unsigned)min(n + 2, g.T - 1) * frame_bytes);
     }
     PDE_AMD_STAMP(1);
 
@@ -538,7 +611,9 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
     }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-      if (RPT * NT == NRQ || j < RPT - 1 || threadIdx.x + j * NT < NRQ) {   // whole waves drop out of the last round
+      const bool mine = ALT ? ((int)threadIdx.x / (NT / 2) == half && (int)threadIdx.x % (NT / 2) + j * NT < NRQ)
+                            : ((int)threadIdx.x + j * NT < NRQ);
+      if (RPT * NT == NRQ || j < RPT - 1 || mine) {   // whole waves drop out of the last round
         fv Gq[P::NE];
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) Gq[k] = vec_zero<W>();
@@ -597,9 +672,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
         for (int px = 0; px < W; ++px) {
           aacc.px = px; aacc.i2 = pi2[q] + px;
 #pragma unroll
-          for (int k = 0; k < P::NE; ++k) { aacc.gm[k] = Gm2[q][px][k]; aacc.gp[k] = Gc[k][px]; }
+          for (int k = 0; k < P::NE; ++k) { aacc.gm[k] = SPLIT_T ? 0.0f : Gm2[q][px][k]; aacc.gp[k] = Gc[k][px]; }
           float gt[P::NF];
-          P::adjoint_time(aacc, gt);
+          if (NO_TIME) { for (int f = 0; f < P::NF; ++f) gt[f] = 0.0f; }
+          else if (SPLIT_T) P::adjoint_time_p(aacc, gt);      // the earlier frame's share is already in Sprev
+          else P::adjoint_time(aacc, gt);
 #pragma unroll
           for (int f = 0; f < P::NF; ++f) out[q][f][px] = Sprev[q][px][f] + gt[f];
         }
@@ -626,10 +703,19 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
       }
 #pragma unroll
       for (int px = 0; px < W; ++px) {
+        if (SPLIT_T && !NO_TIME) {      // frame n's gradient so far: its own frame's terms plus the share of frame n-1's residuals
 #pragma unroll
-        for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = gs[px][f];
+          for (int k = 0; k < P::NE; ++k) aacc.gm[k] = Gm1[q][px][k];
+          float gt[P::NF];
+          P::adjoint_time_m(aacc, gt);
 #pragma unroll
-        for (int k = 0; k < P::NE; ++k) { Gm2[q][px][k] = Gm1[q][px][k]; Gm1[q][px][k] = Gc[k][px]; }
+          for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = gs[px][f] + gt[f];
+        } else {
+#pragma unroll
+          for (int f = 0; f < P::NF; ++f) Sprev[q][px][f] = gs[px][f];
+        }
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) { Gm2[q][px][k] = Gm1[q][px][k]; Gm1[q][px][k] = NO_TIME ? 0.0f : Gc[k][px]; }
       }
     }
     PDE_AMD_STAMP(4);
@@ -649,9 +735,9 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
 #pragma unroll
       for (int q = 0; q < QPT; ++q) {
         if (inside[q]) {
-          const long o = (long)b * g.T * g.S + (long)(n - 1) * g.S + goff[q];
 #pragma unroll
-          for (int f = 0; f < P::NF; ++f) __builtin_nontemporal_store(out[q][f], reinterpret_cast<fv*>(a.g[f] + o));   // streamed: keeps the fields in cache
+          for (int f = 0; f < P::NF; ++f)      // streamed: keeps the fields in cache
+            BufIO<W>::store_nt(out[q][f], gbuf[f], goff[q], (unsigned)(n - 1) * frame_bytes);
         }
       }
     }
@@ -662,8 +748,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), (QuadCfg<P, W>::WPS)) void bwd
   // A branch around the second half would be a path on which, in the compiler's bookkeeping, the first
   // half's loads are still in flight at the loop head, and it would drain the memory queue there.
   for (int n = n0; n <= qb; n += 2) {
-    step(n, stage_a, stage_b);
-    step(n + 1, stage_b, stage_a);      // without DEEP the sets are independent scratch and one of them is optimised away
+    step(n, 0, stage_a, stage_b);
+    step(n + 1, 1, stage_b, stage_a);      // without DEEP the sets are independent scratch and one of them is optimised away
   }
 }
 
@@ -695,6 +781,7 @@ __device__ __forceinline__ void zero_tile_q(float* tile) {
 template <class P, int W>
 struct FrameCfg {
   static constexpr int NT = P::NTQ * 4 / W;
+  static constexpr int NTB = P::NTQB * 4 / W;  // the adjoint may use another workgroup size than the forward kernel
   using TL = Tile<P::QF0, P::QF1, P::QF2, P::RH0, P::RH1, padw<W>(P::RH2)>;
   using TT = Tile<P::QF0, P::QF1, P::QF2, P::RT0, P::RT1, padw<W>(P::RT2)>;
   using TX = Tile<P::QF0, P::QF1, P::QF2, P::XH0, P::XH1, padw<W>(P::XH2)>;
@@ -849,6 +936,7 @@ __global__ __launch_bounds__((FrameCfg<P, W>::NT)) void fwd_frame_q_kernel(const
 template <class P, int W>
 struct StoredCfg {
   static constexpr int NT = P::NTQ * 4 / W;
+  static constexpr int NTB = P::NTQB * 4 / W;  // the adjoint may use another workgroup size than the forward kernel
   using TG = Tile<P::QB0, P::QB1, P::QB2, P::GH0, P::GH1, padw<W>(P::GH2)>;
   using TGT = Tile<P::QB0, P::QB1, P::QB2, P::GT0, P::GT1, padw<W>(P::GT2)>;
   using TA = Tile<P::QB0, P::QB1, P::QB2, P::AH0, P::AH1, padw<W>(P::AH2)>;

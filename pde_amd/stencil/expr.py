@@ -13,6 +13,7 @@ Par(kind, i, name)     runtime scalar: kind 'c' per-instance constant, 's' per-s
 Ref(f, ot, o)          field f at time offset ot and spatial offset o=(o0,o1,o2) (tensor dims -3,-2,-1)
 Aux(a, o)              time-independent auxiliary field a at spatial offset o (never differentiated)
 GRef(k, ot, o)         scaled residual G_k = coef_k * R_k at a relative site (adjoint expressions only)
+Uni(i)                 entry i of a table of hoisted uniform subexpressions (emission only, see hoist_uniforms)
 Add(terms), Mul(factors), Recip(e)
 Sel(c, a, b)           c >= 0 ? a : b      (derivative flows through the selected branch only)
 PSel(p, a, b)          position predicate p ? a : b, p = Pred(axis, k, hi): index == k  (hi: == N-1-k)
@@ -122,6 +123,16 @@ class GRef(E):
 
     def key(self):
         return ("g", self.k, self.ot, self.o)
+
+
+class Uni(E):
+    __slots__ = ("i",)
+
+    def __init__(self, i: int):
+        self.i = i
+
+    def key(self):
+        return ("u", self.i)
 
 
 class Add(E):
@@ -307,7 +318,7 @@ def diff(e: E, r: Ref, memo=None) -> E:
         return memo[k]
     if isinstance(e, Ref):
         res = ONE if e == r else ZERO
-    elif isinstance(e, (Num, Par, Aux, GRef)):
+    elif isinstance(e, (Num, Par, Uni, Aux, GRef)):
         res = ZERO
     elif isinstance(e, Add):
         res = add(*[diff(t, r, memo) for t in e.terms])
@@ -345,7 +356,7 @@ def shift(e: E, dt: int, do: O3, memo=None) -> E:
         res = Aux(e.a, addo(e.o, do))
     elif isinstance(e, GRef):
         res = GRef(e.k, e.ot + dt, addo(e.o, do))
-    elif isinstance(e, (Num, Par)):
+    elif isinstance(e, (Num, Par, Uni)):
         res = e
     elif isinstance(e, Add):
         res = add(*[shift(t, dt, do, memo) for t in e.terms])
@@ -400,6 +411,77 @@ def footprint(exprs: List[E], cls) -> Dict[str, object]:
 
 
 # ---------------------------------------------------------------------------
+# uniform hoisting
+# ---------------------------------------------------------------------------
+# Products and sums of literals, constants and per-sample parameters ("8 * c1", "16 * c4 * nu") are the same
+# at every grid point of a sample.  Left inside the per-point code they cost vector instructions at every
+# point (the device compiler keeps float arithmetic in source order and cannot fold "8 * t * c1" into one
+# multiply by a precomputed "8 c1").  hoist_uniforms() rewrites expressions so that every maximal uniform
+# subexpression, and the uniform part of every mixed product, becomes a reference Uni(i) into a table that the
+# kernels evaluate once per sample.  Values that differ only in sign share an entry.
+
+def is_uniform(e: E) -> bool:
+    if isinstance(e, (Num, Par, Uni)):
+        return True
+    if isinstance(e, (Add, Mul, Recip)):
+        return all(is_uniform(c) for c in children(e))
+    return False
+
+
+class UniformTable:
+    def __init__(self):
+        self.exprs: List[E] = []
+        self.index: Dict[object, int] = {}
+
+    def ref(self, e: E) -> E:
+        """Uni node (possibly negated) standing for the uniform, non-atomic expression e."""
+        if isinstance(e, Mul) and isinstance(e.factors[0], Num) and e.factors[0].v < 0:
+            pos = mul(Num(-e.factors[0].v), *e.factors[1:])
+            return mul(Num(-1.0), pos if isinstance(pos, (Num, Par)) else self.ref(pos))
+        k = e.key()
+        if k not in self.index:
+            self.index[k] = len(self.exprs)
+            self.exprs.append(e)
+        return Uni(self.index[k])
+
+
+def hoist_uniforms(e: E, tab: UniformTable, memo=None) -> E:
+    if memo is None:
+        memo = {}
+    k = e.key()
+    if k in memo:
+        return memo[k]
+    if isinstance(e, (Num, Par, Uni, Ref, Aux, GRef)):
+        res = e
+    elif is_uniform(e):
+        res = tab.ref(e)
+    elif isinstance(e, Add):
+        us = [t for t in e.terms if is_uniform(t)]
+        vs = [hoist_uniforms(t, tab, memo) for t in e.terms if not is_uniform(t)]
+        if us:
+            u = add(*us)
+            vs.append(u if isinstance(u, (Num, Par)) else tab.ref(u))
+        res = add(*vs)
+    elif isinstance(e, Mul):
+        us = [f for f in e.factors if is_uniform(f)]
+        vs = [hoist_uniforms(f, tab, memo) for f in e.factors if not is_uniform(f)]
+        if us:
+            u = mul(*us)
+            vs.insert(0, u if isinstance(u, (Num, Par)) else tab.ref(u))
+        res = mul(*vs)
+    elif isinstance(e, Recip):
+        res = recip(hoist_uniforms(e.e, tab, memo))
+    elif isinstance(e, Sel):
+        res = sel(hoist_uniforms(e.c, tab, memo), hoist_uniforms(e.a, tab, memo), hoist_uniforms(e.b, tab, memo))
+    elif isinstance(e, PSel):
+        res = psel(e.p, hoist_uniforms(e.a, tab, memo), hoist_uniforms(e.b, tab, memo))
+    else:
+        raise TypeError(type(e))
+    memo[k] = res
+    return res
+
+
+# ---------------------------------------------------------------------------
 # C emission with common-subexpression temporaries
 # ---------------------------------------------------------------------------
 
@@ -442,6 +524,8 @@ class Emitter:
             return _flt(e.v) if abs(e.v) in (0.0, 0.5, 1.0, 2.0, 4.0) else f"{a}.k({_flt(e.v)})"
         if isinstance(e, Par):
             return f"{a}.{'c' if e.kind == 'c' else 'sp'}({e.i})"
+        if isinstance(e, Uni):
+            return f"{a}.u({e.i})"
         if isinstance(e, Ref):
             return f"{a}.F({e.f},{e.ot},{e.o[0]},{e.o[1]},{e.o[2]})"
         if isinstance(e, Aux):
@@ -454,7 +538,7 @@ class Emitter:
         k = e.key()
         if k in self.names:
             return self.names[k]
-        if isinstance(e, (Num, Par)):
+        if isinstance(e, (Num, Par, Uni)):
             return self._atom(e)
         if isinstance(e, (Ref, Aux, GRef)):
             s = self._atom(e)

@@ -45,9 +45,11 @@ class Spec:
     quad_bwd: Tuple[int, int, int] = (1, 16, 64)
     threads_quad: int = 256
     waves_per_simd_quad: int = 2
+    threads_quad_bwd: int = 0           # adjoint quad kernel: lanes at width 4 when they differ from threads_quad (0 = same)
     quad_width_fwd: int = 4
     quad_width_bwd: int = 4
     waves_per_simd_quad_fwd: int = 1    # forward quad kernel: compile for this many waves per SIMD (1 = no constraint)
+    hoist_uniforms: bool = True     # precompute products/sums of constants and per-sample parameters once per sample
     quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
 
     # derived
