@@ -166,15 +166,21 @@ def main():
             backend.backward_events, backend.forward_events = bwd_events, fwd_events
             total, losses = loss_step()
             backend.backward_events = backend.forward_events = None
-        return pdist.reduce_scalars({"total": total, **losses})
+        # the step's scalars: one packed all-reduce, started now and joined a step later so that it runs beside the next step
+        return pdist.reduce_scalars_async({"total": total, **losses})
 
     backend.backward_event_pool, backend.forward_event_pool = pool(), pool()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pending = None
     for i in range(args.steps):
-        red = step(i)
+        nxt = step(i)
+        if pending is not None:
+            red = pending.result()
+        pending = nxt
+    red = pending.result()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()

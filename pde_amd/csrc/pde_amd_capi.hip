@@ -180,8 +180,12 @@ struct Ops {
       if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
       hipLaunchKernelGGL((fwd_kernel<P, false>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
     }
-    hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(p->batch), dim3(256), 0, stream, a.partial, sums, (int)items);
-    if (totals) hipLaunchKernelGGL((totals_kernel<P::NE>), dim3(1), dim3(64), 0, stream, sums, totals, p->batch);
+    if (totals && (long)p->batch * items <= 16384) {      // small: one launch does both reductions
+      hipLaunchKernelGGL((finalize_totals_kernel<P::NE>), dim3(1), dim3(1024), 0, stream, a.partial, sums, totals, (int)items, p->batch);
+    } else {
+      hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(p->batch), dim3(256), 0, stream, a.partial, sums, (int)items);
+      if (totals) hipLaunchKernelGGL((totals_kernel<P::NE>), dim3(1), dim3(64), 0, stream, sums, totals, p->batch);
+    }
     return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
   }
 

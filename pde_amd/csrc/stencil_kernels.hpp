@@ -389,6 +389,51 @@ __global__ __launch_bounds__(64) void totals_kernel(const double* __restrict__ s
   if (threadIdx.x == 0) totals[NE] = tot;
 }
 
+// Both of the above in one launch for small problems: one workgroup of 16 waves; wave w sums the partials of
+// samples w, w+16, ... (lanes stride over a sample's items), then thread 0 adds the per-wave totals in wave order.
+// Fixed order, so repeatable; it saves a launch and the gap between two tiny kernels.
+template <int NE>
+__global__ __launch_bounds__(1024) void finalize_totals_kernel(const double* __restrict__ partial, double* __restrict__ sums,
+                                                               float* __restrict__ totals, int items, int B) {
+  __shared__ double s_tot[16 * NE];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double tot[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) tot[k] = 0.0;
+  for (int b = wv; b < B; b += 16) {
+    double acc[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+    const double* p = partial + (long)b * items * NE;
+    for (int i = lane; i < items; i += 64) {
+#pragma unroll
+      for (int k = 0; k < NE; ++k) acc[k] += p[(long)i * NE + k];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double s = wave_sum(acc[k]);      // complete in lane 0
+      if (lane == 0) { sums[(long)b * NE + k] = s; tot[k] += s; }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) s_tot[wv * NE + k] = tot[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      double s = 0.0;
+      for (int w = 0; w < 16; ++w) s += s_tot[w * NE + k];
+      const float f = (float)s;
+      totals[k] = f;
+      t += f;
+    }
+    totals[NE] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward, stored-residual mode: one workgroup = (sample, output frame tq, tile)
 //   G_k = coef[b][k][frame] * R_k is staged in LDS (with the adjoint's halo) and gathered

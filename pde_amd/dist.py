@@ -21,15 +21,41 @@ def shard_batch(n: int, rank: int, world: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
+class PendingScalars:
+    """Handle of a packed all-reduce in flight; result() waits for it (on the current stream) and unpacks."""
+
+    def __init__(self, keys, buf, work, scale):
+        self._keys, self._buf, self._work, self._scale = keys, buf, work, scale
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            if self._scale != 1.0:
+                self._buf = self._buf * self._scale
+        return {k: self._buf[i] for i, k in enumerate(self._keys)}
+
+
+def reduce_scalars_async(values: Dict[str, torch.Tensor], op: str = "mean", group=None) -> PendingScalars:
+    """Start ONE all-reduce over a dict of 0-dim tensors and return at once; the collective runs beside whatever is enqueued
+    next (the following step), and `.result()` joins it.  The values are copied into the packed buffer first, so the caller
+    may overwrite them."""
+    if op not in ("mean", "sum"):
+        raise ValueError("op must be 'mean' or 'sum'")
+    keys = list(values)
+    if not keys:
+        return PendingScalars(keys, torch.empty(0, dtype=torch.float64), None, 1.0)
+    buf = torch.stack([values[k].detach().reshape(()) for k in keys]).to(torch.float64)     # two small kernels, whatever the count
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return PendingScalars(keys, buf, None, 1.0)
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return PendingScalars(keys, buf, work, 1.0 / dist.get_world_size(group) if op == "mean" else 1.0)
+
+
 def reduce_scalars(values: Dict[str, torch.Tensor], op: str = "mean", group=None) -> Dict[str, torch.Tensor]:
     """All-reduce a dict of 0-dim tensors with a single collective; identity when not distributed."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if op not in ("mean", "sum"):
+            raise ValueError("op must be 'mean' or 'sum'")
         return {k: v.detach() for k, v in values.items()}
-    keys = list(values)
-    buf = torch.stack([values[k].detach().to(torch.float64).reshape(()) for k in keys])
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    if op == "mean":
-        buf = buf / dist.get_world_size(group)
-    elif op != "sum":
-        raise ValueError("op must be 'mean' or 'sum'")
-    return {k: buf[i] for i, k in enumerate(keys)}
+    return reduce_scalars_async(values, op, group).result()

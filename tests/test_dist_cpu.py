@@ -46,6 +46,10 @@ def _case_reduce(rank, world):
     vals = {"total": torch.tensor(1.0 + rank), "continuity": torch.tensor(10.0 * (rank + 1))}
     mean = pdist.reduce_scalars(vals)
     tot = pdist.reduce_scalars(vals, op="sum")
+    pend = pdist.reduce_scalars_async(vals)          # started, values overwritten, joined later
+    vals["total"].fill_(-1.0)
+    late = pend.result()
+    assert {k: float(v) for k, v in late.items()} == {k: float(v) for k, v in mean.items()}
     return {k: float(v) for k, v in mean.items()}, {k: float(v) for k, v in tot.items()}
 
 
