@@ -261,6 +261,68 @@ __global__ __launch_bounds__(256) void scatter_kernel(const GatherArgs a, float*
   }
 }
 
+// Tiled forms of the two kernels above for the usual case (few channels, 16-byte aligned frames).  The channel-last
+// tensor is only ever touched with whole float4 rows of a 256-point chunk, which pass through an LDS image
+// [256][C]; the per-channel side reads or writes one float per thread, consecutive points in consecutive lanes.
+// A work item is (frame, chunk of 256 points).  Streaming rate instead of one strided access per point and channel.
+constexpr int TILE_PTS = 256;
+
+__global__ __launch_bounds__(TILE_PTS) void gather_tile_kernel(const GatherArgs a) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const unsigned C = (unsigned)a.C, tid = threadIdx.x;
+  const long chunks = (a.S + TILE_PTS - 1) / TILE_PTS, items = a.B * (a.T_out + 1) * chunks;
+  for (long w = blockIdx.x; w < items; w += gridDim.x) {
+    const long frame = w / chunks, b = frame / (a.T_out + 1), t = frame % (a.T_out + 1);
+    const unsigned p0 = (unsigned)(w % chunks) * TILE_PTS;
+    const unsigned np = min((unsigned)TILE_PTS, (unsigned)a.S - p0);
+    const float* src = (t == 0 ? a.input + (b * a.T_in) * a.S * C : a.output + (b * a.T_out + (t - 1)) * a.S * C) + (long)p0 * C;
+    const unsigned n4 = np * C / 4;
+    for (unsigned i = tid; i < n4; i += TILE_PTS) reinterpret_cast<f4*>(tile)[i] = reinterpret_cast<const f4*>(src)[i];
+    __syncthreads();
+    if (tid < np) {
+      const long dst = frame * a.S + field_site(a, p0 + tid);
+      for (int f = 0; f < a.nf; ++f) a.fields[f][dst] = tile[tid * C + (unsigned)a.ch[f]];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(TILE_PTS) void scatter_tile_kernel(const GatherArgs a, float* __restrict__ grad_output) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const unsigned C = (unsigned)a.C, tid = threadIdx.x;
+  for (unsigned i = tid; i < TILE_PTS * C; i += TILE_PTS) tile[i] = 0.0f;      // the other channels stay zero for good
+  __syncthreads();
+  const long chunks = (a.S + TILE_PTS - 1) / TILE_PTS, items = a.B * a.T_out * chunks;
+  for (long w = blockIdx.x; w < items; w += gridDim.x) {
+    const long frame = w / chunks, b = frame / a.T_out, t = frame % a.T_out;
+    const unsigned p0 = (unsigned)(w % chunks) * TILE_PTS;
+    const unsigned np = min((unsigned)TILE_PTS, (unsigned)a.S - p0);
+    if (tid < np) {
+      const long src = (b * (a.T_out + 1) + t + 1) * a.S + field_site(a, p0 + tid);
+      for (int f = 0; f < a.nf; ++f) {
+        float v = a.gfields[f][src];
+        bool again = false;      // a channel listed more than once collects all its gradients
+        for (int g = 0; g < f; ++g) again = again || a.ch[g] == a.ch[f];
+        if (again) v += tile[tid * C + (unsigned)a.ch[f]];
+        tile[tid * C + (unsigned)a.ch[f]] = v;
+      }
+    }
+    __syncthreads();
+    f4* dst = reinterpret_cast<f4*>(grad_output + (frame * a.S + p0) * C);
+    const unsigned n4 = np * C / 4;
+    for (unsigned i = tid; i < n4; i += TILE_PTS) __builtin_nontemporal_store(reinterpret_cast<const f4*>(tile)[i], dst + i);   // streamed once
+    __syncthreads();
+  }
+}
+
+// the tiled kernels need whole float4 rows per chunk and frame, and an LDS image of 256 points
+inline bool tile_path_ok(long S, int C, const void* p0, const void* p1) {
+  return C <= 40 && (S * C) % 4 == 0 && (TILE_PTS * C) % 4 == 0 && S < (1L << 31) &&
+         ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1)) & 15) == 0;
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP; }
 
 }  // namespace
@@ -377,6 +439,12 @@ int pde_amd_gather_fields(const float* output, const float* input, int64_t B, in
   for (int f = 0; f < n_fields; ++f) { if (!fields[f]) return PDE_AMD_EINVAL; a.fields[f] = fields[f]; }
   const long npts = B * (T_out + 1) * S;
   if (npts == 0) return PDE_AMD_OK;
+  if (tile_path_ok(S, C, output, input)) {
+    long items = B * (T_out + 1) * ((S + TILE_PTS - 1) / TILE_PTS);
+    if (items > 256 * 32) items = 256 * 32;
+    hipLaunchKernelGGL(gather_tile_kernel, dim3((unsigned)items), dim3(TILE_PTS), (size_t)TILE_PTS * C * sizeof(float), (hipStream_t)stream, a);
+    return check_launch();
+  }
   long nb = (npts + 255) / 256;
   if (nb > 65536) nb = 65536;
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
@@ -393,6 +461,12 @@ int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int6
   for (int f = 0; f < n_fields; ++f) { if (!field_grads[f]) return PDE_AMD_EINVAL; a.gfields[f] = field_grads[f]; }
   const long n = B * T_out * S * (long)C;
   if (n == 0) return PDE_AMD_OK;
+  if (tile_path_ok(S, C, grad_output, grad_output)) {
+    long items = B * T_out * ((S + TILE_PTS - 1) / TILE_PTS);
+    if (items > 256 * 32) items = 256 * 32;
+    hipLaunchKernelGGL(scatter_tile_kernel, dim3((unsigned)items), dim3(TILE_PTS), (size_t)TILE_PTS * C * sizeof(float), (hipStream_t)stream, a, grad_output);
+    return check_launch();
+  }
   const long frame_elems = S * (long)C;
   if (frame_elems >= (1L << 31) || B * T_out > 65535) return PDE_AMD_ESHAPE;
   const bool vec = frame_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_output) & 15) == 0;

@@ -116,11 +116,12 @@ def check_metric_func(dev, tag):
             assert _rel(r.cpu().numpy(), want) <= 2e-5, (tag, mode, i, _rel(r.cpu().numpy(), want))
 
 
-def check_gather(dev, transpose, spatial=(6, 8)):
+def check_gather(dev, transpose, spatial=(6, 8), C=18, chans=None):
     gen = torch.Generator().manual_seed(11)
-    out = torch.randn(2, 3, *spatial, 18, generator=gen)
-    inp = torch.randn(2, 4, *spatial, 18, generator=gen)
-    chans = (0, 1, 15) if not transpose else (0, 1, 3)
+    out = torch.randn(2, 3, *spatial, C, generator=gen)
+    inp = torch.randn(2, 4, *spatial, C, generator=gen)
+    if chans is None:
+        chans = (0, 1, 15) if not transpose else (0, 1, 3)
     o = out.clone().to(dev).requires_grad_(True)
     fields = PG.gather_fields(o, inp.to(dev), chans, transpose=transpose)
     o64 = out.double().requires_grad_(True)

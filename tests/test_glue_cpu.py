@@ -99,6 +99,7 @@ def test_gather_host_logic(transpose):
 def test_gather_3d_and_1d_host_logic():
     GC.check_gather(CPU, False, (3, 4, 5))
     GC.check_gather(CPU, False, (9,))
+    GC.check_gather(CPU, False, (7, 6), 18, (2, 2, 15))      # a channel listed twice
 
 
 def test_compute_pde_loss_host_logic():

@@ -52,6 +52,18 @@ def test_gather_odd_extents(spatial):
     GC.check_gather(DEV, len(spatial) == 2, spatial)
 
 
+@pytest.mark.parametrize("spatial,C,chans,transpose", [
+    ((20, 13), 18, (0, 1, 15), False),      # two chunks of 256 points, the second with 4
+    ((20, 13), 18, (0, 1, 3), True),
+    ((33, 32), 18, (2, 2, 15), False),      # a channel listed twice collects both gradients
+    ((24, 24), 6, (5, 0), False),
+    ((16, 16), 44, (43, 0, 7), False),      # too many channels for the tiled kernels
+    ((6, 5, 14), 18, (17, 0, 9), False),
+])
+def test_gather_tiled_and_fallback(spatial, C, chans, transpose):
+    GC.check_gather(DEV, transpose, spatial, C, chans)
+
+
 def test_compute_pde_loss():
     GC.check_compute_pde_loss(DEV)
 
