@@ -24,5 +24,6 @@ from .glue import (  # noqa: F401
     compute_pde_loss_rayleigh_benard, compute_pde_loss_shear_flow, compute_pde_loss_burgers_1d, compute_pde_loss_gray_scott,
     compute_pde_loss_burgers_3d, compute_pde_loss_heat_3d,
 )
+from .sink import shared_grad  # noqa: F401
 
 __version__ = "0.1.0"

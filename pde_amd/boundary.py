@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from . import reductions as R
+from .sink import sink_of
 
 CH_VX, CH_VY = 0, 1      # finetune/train_ns_incom_lora_v3.py:74-75
 
@@ -64,9 +65,9 @@ class _TermSums(torch.autograd.Function):
     """sums[t] = sum of squared term values, fp64 [n_terms]; differentiable w.r.t. pred."""
 
     @staticmethod
-    def forward(ctx, pred, target, ts: TermSet, outer: int):
+    def forward(ctx, pred, target, ts: TermSet, outer: int, sink):
         be = R.get_backend()
-        ctx.ts, ctx.outer = ts, outer
+        ctx.ts, ctx.outer, ctx.sink = ts, outer, sink
         ctx.save_for_backward(pred, target if target is not None else pred.new_empty(0))
         ctx.has_target = target is not None
         return be.terms_forward(pred, target, outer, ts.dims, ts.terms, ts.indices(pred.device))
@@ -75,10 +76,14 @@ class _TermSums(torch.autograd.Function):
     def backward(ctx, gsums):
         pred, target = ctx.saved_tensors
         be = R.get_backend()
+        args = (pred, target if ctx.has_target else None, ctx.outer, ctx.ts.dims, ctx.ts.terms,
+                ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous())
+        if ctx.sink is not None:      # added into the shared buffer of `pred` once that exists
+            ctx.sink.terms.append(args)
+            return None, None, None, None, None
         grad = torch.zeros_like(pred)
-        be.terms_backward(pred, target if ctx.has_target else None, ctx.outer, ctx.ts.dims, ctx.ts.terms,
-                          ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous(), grad)
-        return grad, None, None, None
+        be.terms_backward(*args, grad)
+        return grad, None, None, None, None
 
 
 def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
@@ -92,7 +97,7 @@ def _term_means(pred, target, ts: TermSet, n_groups: int) -> List[torch.Tensor]:
     pred = _prep(pred, "pred")
     target = _prep(target, "target") if target is not None else None
     outer = int(pred.shape[0]) * int(pred.shape[1])
-    sums = _TermSums.apply(pred, target, ts, outer)
+    sums = _TermSums.apply(pred, target, ts, outer, sink_of(pred))
     out = []
     for g in range(n_groups):
         sel = [i for i, gg in enumerate(ts.groups) if gg == g]

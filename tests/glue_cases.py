@@ -157,3 +157,44 @@ def check_compute_pde_loss(dev):
     fn = PG.create_pde_loss(cfg, dev)
     t2, _ = PG.compute_pde_loss_generic(o.detach(), inp.to(dev), fn, cfg, {"nu": nu})
     assert abs(float(t2) - float(want.detach())) <= RTOL * float(want.detach())
+
+
+def check_shared_grad(dev):
+    """every loss of one training step on one tagged output: same values, and the gradient written through the shared buffer
+    equals the sum autograd builds from the separate full-size gradients (up to the order of a few fp32 additions)"""
+    import pde_amd
+    gen = torch.Generator().manual_seed(5)
+    B, T, H, W, C = 2, 4, 20, 16, 18
+    out0 = torch.randn(B, T, H, W, C, generator=gen).to(dev)
+    inp = torch.randn(B, 3, H, W, C, generator=gen).to(dev)
+    tgt = torch.randn(B, T, H, W, C, generator=gen).to(dev)
+    mask = torch.zeros(B, C); mask[:, [0, 1, 15]] = 1
+    nu = torch.tensor([0.02, 0.07]).to(dev)
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=W, ny=H, dt=0.01).to(dev)
+
+    def losses(o):
+        pde, parts = PG.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)
+        bc = PB.compute_boundary_loss(o, tgt, mask.to(dev), 2)
+        ns = PB.compute_noslip_loss(o)
+        seam = PB.compute_patch_boundary_loss(o, mask.to(dev), patch_size=4)
+        extra = (o[..., 3] ** 2).mean()          # an ordinary torch consumer of the same tensor
+        return 1e-6 * pde + 0.5 * bc + 0.25 * ns + 0.125 * seam + extra, (pde, bc, ns, seam)
+
+    a = out0.clone().requires_grad_(True)
+    la, pa = losses(a)
+    la.backward()
+    b = out0.clone().requires_grad_(True)
+    lb, pb = losses(pde_amd.shared_grad(b))
+    lb.backward()
+    for x, y in zip(pa, pb):
+        assert torch.equal(x.detach().cpu(), y.detach().cpu())
+    ga, gb = a.grad.cpu().double(), b.grad.cpu().double()
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
+    # a second step reuses nothing of the first; no-grad and non-fp32 inputs come back untagged
+    with torch.no_grad():
+        assert pde_amd.shared_grad(b) is b
+    assert pde_amd.shared_grad(b.detach()) is not None
+    c = out0.clone().requires_grad_(True)
+    lc, _ = losses(pde_amd.shared_grad(c))
+    lc.backward()
+    assert torch.equal(c.grad.cpu(), b.grad.cpu())

@@ -121,3 +121,7 @@ def test_faces_variant_index_error():
     x = torch.zeros(1, 1, 4, 8, 4, 18)
     with pytest.raises(IndexError):
         PB.compute_boundary_loss(x, x, m, variant="faces")
+
+
+def test_shared_grad_host_logic():
+    GC.check_shared_grad(CPU)

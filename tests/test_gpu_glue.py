@@ -135,3 +135,7 @@ def test_patch_seam_ragged_against_oracle():
 def test_cpu_tensor_rejected():
     with pytest.raises(RuntimeError, match="HIP device"):
         PM.compute_vrmse(torch.zeros(1, 1, 4, 4, 18), torch.zeros(1, 1, 4, 4, 18), torch.ones(18))
+
+
+def test_shared_grad():
+    GC.check_shared_grad(DEV)

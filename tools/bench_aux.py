@@ -53,3 +53,16 @@ def bc():
     pde_amd.compute_boundary_loss(o2, tgt, m2, 1).backward()
 ms = timeit(bc)
 print(f"compute_boundary_loss fwd+bwd (includes zero-filling the {4 * out.numel() / 1e6:.0f} MB gradient): {ms:.3f} ms")
+
+# the physics losses of one training step on the model output: residual loss through the channel gather + boundary strips
+fn = pde_amd.TaylorGreen2DPDELoss(nx=256, ny=256, dt=0.01).to(dev)
+nu = torch.rand(B, device=dev) * 0.09 + 0.01
+def train_losses(shared):
+    o2.grad = None
+    o = pde_amd.shared_grad(o2) if shared else o2
+    pde, _ = pde_amd.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)
+    bc_l = pde_amd.compute_boundary_loss(o, tgt, m2, 1)
+    (1e-3 * pde + 0.1 * bc_l).backward()
+for shared in (False, True):
+    ms = timeit(lambda: train_losses(shared))
+    print(f"step losses (gather + TG residual + boundary strips) fwd+bwd, {'one shared gradient buffer' if shared else 'separate gradients added by autograd'}: {ms:.3f} ms")
