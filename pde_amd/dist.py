@@ -24,10 +24,12 @@ def shard_batch(n: int, rank: int, world: int):
 class PendingScalars:
     """Handle of a packed all-reduce in flight; result() waits for it (on the current stream) and unpacks."""
 
-    def __init__(self, keys, buf, work, scale):
-        self._keys, self._buf, self._work, self._scale = keys, buf, work, scale
+    def __init__(self, keys, buf, work, scale, values=None):
+        self._keys, self._buf, self._work, self._scale, self._values = keys, buf, work, scale, values
 
     def result(self) -> Dict[str, torch.Tensor]:
+        if self._values is not None:      # single process: nothing was packed
+            return self._values
         if self._work is not None:
             self._work.wait()
             self._work = None
@@ -38,16 +40,16 @@ class PendingScalars:
 
 def reduce_scalars_async(values: Dict[str, torch.Tensor], op: str = "mean", group=None) -> PendingScalars:
     """Start ONE all-reduce over a dict of 0-dim tensors and return at once; the collective runs beside whatever is enqueued
-    next (the following step), and `.result()` joins it.  The values are copied into the packed buffer first, so the caller
-    may overwrite them."""
+    next (the following step), and `.result()` joins it.  With more than one rank the values are copied into the packed buffer first, so the
+    caller may overwrite them; a single process gets its own values back, unpacked and uncopied."""
     if op not in ("mean", "sum"):
         raise ValueError("op must be 'mean' or 'sum'")
     keys = list(values)
     if not keys:
         return PendingScalars(keys, torch.empty(0, dtype=torch.float64), None, 1.0)
-    buf = torch.stack([values[k].detach().reshape(()) for k in keys]).to(torch.float64)     # two small kernels, whatever the count
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return PendingScalars(keys, buf, None, 1.0)
+        return PendingScalars(keys, None, None, 1.0, {k: v.detach() for k, v in values.items()})
+    buf = torch.stack([values[k].detach().reshape(()) for k in keys]).to(torch.float64)     # two small kernels, whatever the count
     work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return PendingScalars(keys, buf, work, 1.0 / dist.get_world_size(group) if op == "mean" else 1.0)
 
