@@ -563,7 +563,9 @@ class Emitter:
         elif isinstance(e, Recip):
             s = "(1.0f / " + self.expr(e.e) + ")"
         elif isinstance(e, Sel):
-            s = f"(({self.expr(e.c)}) >= 0.0f ? {self.expr(e.a)} : {self.expr(e.b)})"
+            # a call, so that both sides are values before the choice: the device compiler then emits one select;
+            # with the ?: operator it builds divergent branches around the few multiply-adds of each side
+            s = f"{self.acc}.sel({self.expr(e.c)}, {self.expr(e.a)}, {self.expr(e.b)})"
         elif isinstance(e, PSel):
             fn = "ath" if e.p.hi else "at"
             s = f"({self.acc}.{fn}({e.p.axis},{e.p.k}) ? {self.expr(e.a)} : {self.expr(e.b)})"
