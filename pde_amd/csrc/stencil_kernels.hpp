@@ -127,6 +127,7 @@ struct SiteBase {
   __device__ __forceinline__ float sp(int i) const { return spv[i]; }
   __device__ __forceinline__ float u(int i) const { return uv[i]; }
   static __device__ __forceinline__ float sel(float c, float x, float y) { return c >= 0.0f ? x : y; }   // upwind choice
+  static __device__ __forceinline__ float pick(bool p, float x, float y) { return p ? x : y; }            // wall / ghost-cell choice
   // VG: keep the uniform values in vector registers.  A VALU instruction with a scalar-register operand
   // issues at half the rate of one whose operands are all vector registers (measured: 4 vs 2-2.5 cycles per
   // wave64 instruction), and these values are operands of most of the generated arithmetic.

@@ -568,7 +568,7 @@ class Emitter:
             s = f"{self.acc}.sel({self.expr(e.c)}, {self.expr(e.a)}, {self.expr(e.b)})"
         elif isinstance(e, PSel):
             fn = "ath" if e.p.hi else "at"
-            s = f"({self.acc}.{fn}({e.p.axis},{e.p.k}) ? {self.expr(e.a)} : {self.expr(e.b)})"
+            s = f"{self.acc}.pick({self.acc}.{fn}({e.p.axis},{e.p.k}), {self.expr(e.a)}, {self.expr(e.b)})"
         else:
             raise TypeError(type(e))
         # loads and shared subtrees become named temporaries
