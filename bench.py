@@ -116,12 +116,14 @@ def main():
 
     backend = PF.get_backend()
 
+    one = torch.ones((), device=dev)
+
     def loss_step():
         """forward + backward of the loss through the nn.Module API; gradients land in fields[i].grad"""
         for f in fields:
             f.grad = None
         total, losses = loss_fn(*fields, nu=nu)
-        total.backward()
+        total.backward(gradient=one)      # the upstream gradient of the loss: a resident 1.0 instead of a fill launch per step
         # detached: nothing of the autograd graph (and its per-leaf accumulation nodes, which remember the stream they
         # were created on) outlives the step, so a later capture on another stream starts clean
         return total.detach(), {k: v.detach() for k, v in losses.items()}
