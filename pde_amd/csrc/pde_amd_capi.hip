@@ -42,6 +42,9 @@ static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (
 // (each re-reads a few frames at its ends) when they do not.
 static inline int pick_chunk(long blocks_per_chunking, int frames) {
   const long want = 768;   // about three workgroups per CU
+#ifdef PDE_AMD_DIAG_ONLY
+  if (getenv("PDE_AMD_CHUNK")) return atoi(getenv("PDE_AMD_CHUNK"));
+#endif
   int nchunk = (int)((want + blocks_per_chunking - 1) / blocks_per_chunking);
   if (nchunk < 1) nchunk = 1;
   int chunk = cdiv(frames, nchunk);
