@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--mode", default="fused", choices=["fused", "auto"],
+                    help="loss module backward_mode: 'fused' = loss and gradient in one pass of the adjoint kernel (it recomputes "
+                         "every residual anyway), 'auto' = forward kernel, then adjoint kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,6 +116,7 @@ def main():
     gnu = torch.Generator(device=dev).manual_seed(99 + rank)
     nu = 0.01 + 0.09 * torch.rand(B, generator=gnu, device=dev)
     loss_fn = pde_amd.TaylorGreen2DPDELoss(nx=W, ny=H, dt=0.01, eq_scales=EQ_SCALES).to(dev)
+    loss_fn.backward_mode = args.mode      # upstream_hint stays 1.0: the step backpropagates `total` itself
 
     backend = PF.get_backend()
 
@@ -198,8 +202,8 @@ def main():
 
     if rank == 0:
         k_ms = sorted(x.elapsed_time(y) for x, y in bwd_events)
-        f_ms = sorted(x.elapsed_time(y) for x, y in fwd_events)
-        bwd_avg = sum(k_ms) / len(k_ms)                   # the adjoint kernel launch alone
+        f_ms = sorted(x.elapsed_time(y) for x, y in fwd_events)      # empty in fused mode: there is no forward launch
+        bwd_avg = sum(k_ms) / len(k_ms)                   # the adjoint kernel launch (fused mode: plus the 4 us reduction of the loss partials)
         e_in = 3 * B * T * H * W
         bwd_bytes = 8 * e_in            # adjoint: read every field once, write every gradient once
         achieved = bwd_bytes / (bwd_avg * 1e-3) / 1e9
@@ -210,14 +214,16 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank,
-                       "launch": "hip-graph replay, every 5th step eager with kernel events" if graph is not None else "eager"},
+                       "launch": "hip-graph replay, every 5th step eager with kernel events" if graph is not None else "eager",
+                       "backward_mode": args.mode},
             "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step, HIP events "
-                                                     "on the launch stream around it)",
+                                                     "on the launch stream around it" + ("; in fused mode it also sums the loss, and the "
+                                                     "events include the small reduction kernel that follows)" if args.mode == "fused" else ")"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("bwd_march_q_kernel"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
                          "median_ms": k_ms[len(k_ms) // 2], "timed_launches": len(k_ms),
-                         "fwd_median_ms": f_ms[len(f_ms) // 2],
-                         "fwd_algorithmic_bytes": 4 * e_in, "fwd_traffic": measured_traffic("fwd_march_q_kernel")},
+                         **({"fwd_median_ms": f_ms[len(f_ms) // 2], "fwd_algorithmic_bytes": 4 * e_in,
+                             "fwd_traffic": measured_traffic("fwd_march_q_kernel")} if f_ms else {})},
             "loss": float(red["total"]),
         }
         if world == 1 and not args.no_cpu_baseline:

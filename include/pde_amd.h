@@ -90,6 +90,26 @@ int pde_amd_residual_backward(const pde_amd_problem* prob,
                               const float* const* resid_in, float* const* grads,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* One training step of the same functions in one call: the loss (sums / totals as in pde_amd_residual_forward) and
+ * the gradient of `upstream_total * totals[n_eqs]` w.r.t. every field (as pde_amd_residual_backward with only
+ * upstream[n_eqs] set), i.e. what `total, losses = loss_fn(...); (c * total).backward()` needs
+ * (finetune/train_taylor_green_2d_lora_v3.py:506-530).  Where the vector adjoint applies it is a single pass over
+ * the fields: that kernel recomputes every residual anyway and adds up weight * R^2 on the way; elsewhere the
+ * forward and the backward kernels run one after the other.  upstream_total is a device scalar, read on the device.
+ * Needs pde_amd_pde_info.can_recompute. */
+int pde_amd_residual_forward_backward(const pde_amd_problem* prob,
+                                      const float* const* fields, const float* const* aux,
+                                      const float* const* sparams, const float* weights,
+                                      const float* upstream_total, double* sums, float* totals,
+                                      float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* grads[f][i] *= *upstream / *assumed for n_fields arrays of `elements` floats; nothing is read or written when the
+ * two device scalars are equal (decided on the device, no host synchronisation).  It turns the gradients that
+ * pde_amd_residual_forward_backward produced for an assumed upstream value into those for the value autograd
+ * delivers later (e.g. lambda_pde, or a loss scaler's factor).  No counterpart in the reference. */
+int pde_amd_rescale_gradients(float* const* grads, int32_t n_fields, int64_t elements, const float* upstream,
+                              const float* assumed, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Channel-last evaluation metrics.
  *

@@ -18,7 +18,30 @@ struct PdeVTable {
              double*, float*, float* const*, void*, size_t, hipStream_t);
   int (*bwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
              const float* const*, const double*, const float* const*, float* const*, void*, size_t, hipStream_t);
+  int (*fwd_bwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
+                 const float*, double*, float*, float* const*, void*, size_t, hipStream_t);
 };
+
+// grads[f] *= g / hint, skipped by every workgroup when the two are equal (both are device scalars)
+struct ScaleArgs {
+  float* p[PDE_AMD_MAX_FIELDS];
+  int n;
+  long n4;      // float4s (or, unaligned, floats) per field
+  const float* g;
+  const float* hint;
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void scale_kernel(const ScaleArgs a) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const float r = ldc(a.g, 0) / ldc(a.hint, 0);
+  if (r == 1.0f) return;
+  for (int f = 0; f < a.n; ++f) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (long)gridDim.x * 256) {
+      if (VEC == 4) { f4* q = reinterpret_cast<f4*>(a.p[f]); q[i] = q[i] * r; }
+      else a.p[f][i] *= r;
+    }
+  }
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -183,13 +206,59 @@ struct Ops {
       if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
       hipLaunchKernelGGL((fwd_kernel<P, false>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
     }
-    if (totals && (long)p->batch * items <= 16384) {      // small: one launch does both reductions
-      hipLaunchKernelGGL((finalize_totals_kernel<P::NE>), dim3(1), dim3(1024), 0, stream, a.partial, sums, totals, (int)items, p->batch);
-    } else {
-      hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(p->batch), dim3(256), 0, stream, a.partial, sums, (int)items);
-      if (totals) hipLaunchKernelGGL((totals_kernel<P::NE>), dim3(1), dim3(64), 0, stream, sums, totals, p->batch);
-    }
+    reduce_partials(a.partial, sums, totals, items, p->batch, stream);
     return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+  }
+
+  static void reduce_partials(const double* partial, double* sums, float* totals, long items, int batch, hipStream_t stream) {
+    if (totals && (long)batch * items <= 16384) {      // small: one launch does both reductions
+      hipLaunchKernelGGL((finalize_totals_kernel<P::NE>), dim3(1), dim3(1024), 0, stream, partial, sums, totals, (int)items, batch);
+    } else {
+      hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(batch), dim3(256), 0, stream, partial, sums, (int)items);
+      if (totals) hipLaunchKernelGGL((totals_kernel<P::NE>), dim3(1), dim3(64), 0, stream, sums, totals, batch);
+    }
+  }
+
+  // Loss and gradient of one training step in one pass where the vector adjoint applies (it recomputes every residual
+  // anyway and adds up weight * R^2 on the way); otherwise the forward and the backward launch one after the other.
+  static int fwd_bwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
+                     const float* const* sparams, const float* weights, const float* upstream_total, double* sums,
+                     float* totals, float* const* grads, void* ws, size_t ws_bytes_given, hipStream_t stream) {
+    int st = check(p);
+    if (st) return st;
+    if (!sums || !grads || !upstream_total) return PDE_AMD_EINVAL;
+    const long tr = p->frames - P::TLO - P::THI;
+    bool fused = false;
+    if constexpr (QuadCfg<P, P::QWB>::BWD_OK) {
+      if (tr > 0 && fields && weights && (!P::NA || aux) && (!P::NSP || sparams) && ws && quad_addressable(p) &&
+          p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) && aligned_vec<P::NF, P::QWB>(grads) &&
+          (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
+        for (int f = 0; f < P::NF; ++f)
+          if (!grads[f]) return PDE_AMD_EINVAL;
+        Args a;
+        fill_args(a, p, fields, aux, sparams);
+        fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);
+        a.wt = weights;
+        a.ups[P::NE] = upstream_total;
+        for (int f = 0; f < P::NF; ++f) a.g[f] = grads[f];
+        a.partial = reinterpret_cast<double*>(ws);
+        const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
+        a.chunk = pick_chunk(p->batch * qtiles, p->frames);
+        const long items = (long)cdiv(p->frames, a.chunk) * qtiles;
+        const long nwg = (long)p->batch * items;
+        if (nwg < (1L << 31) && (size_t)nwg * P::NE * sizeof(double) <= ws_bytes_given) {
+          hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
+          reduce_partials(a.partial, sums, totals, items, p->batch, stream);
+          fused = true;
+        }
+      }
+    }
+    if (fused) return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+    st = fwd(p, fields, aux, sparams, weights, sums, totals, nullptr, ws, ws_bytes_given, stream);
+    if (st) return st;
+    const float* ups[MAXE + 1] = {};
+    ups[P::NE] = upstream_total;
+    return bwd(p, fields, aux, sparams, weights, ups, nullptr, nullptr, grads, ws, ws_bytes_given, stream);
   }
 
   static int bwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
@@ -279,7 +348,7 @@ struct Ops {
     v.info.halo[2] = P::RH2 > P::RT2 ? P::RH2 : P::RT2;
     v.info.can_recompute = BwdMarchFits<P>::value ? 1 : 0;   // the quad adjoint is an accelerated form of the same mode
     v.info.name = P::NAME;
-    v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd;
+    v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd; v.fwd_bwd = &fwd_bwd;
     return v;
   }
 };
@@ -351,6 +420,38 @@ int pde_amd_residual_backward(const pde_amd_problem* prob, const float* const* f
   if (!v) return PDE_AMD_EINVAL;
   return v->bwd(prob, fields, aux, sparams, weights, upstream, upstream_sums, resid_in, grads, workspace,
                 workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int pde_amd_residual_forward_backward(const pde_amd_problem* prob, const float* const* fields, const float* const* aux,
+                                      const float* const* sparams, const float* weights, const float* upstream_total,
+                                      double* sums, float* totals, float* const* grads, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
+  if (!v) return PDE_AMD_EINVAL;
+  return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
+int pde_amd_rescale_gradients(float* const* grads, int32_t n_fields, int64_t elements, const float* upstream,
+                              const float* assumed, void* stream) {
+  if (!grads || !upstream || !assumed || n_fields < 0 || n_fields > PDE_AMD_MAX_FIELDS || elements < 0) return PDE_AMD_EINVAL;
+  if (n_fields == 0 || elements == 0) return PDE_AMD_OK;
+  ScaleArgs a;
+  a.n = n_fields; a.g = upstream; a.hint = assumed;
+  bool vec = true;
+  for (int f = 0; f < n_fields; ++f) {
+    if (!grads[f]) return PDE_AMD_EINVAL;
+    a.p[f] = grads[f];
+    vec = vec && (reinterpret_cast<uintptr_t>(grads[f]) & 15) == 0;
+  }
+  vec = vec && elements % 4 == 0;
+  a.n4 = vec ? elements / 4 : elements;
+  long nb = (a.n4 + 256 * 8 - 1) / (256 * 8);
+  if (nb > 4096) nb = 4096;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec) hipLaunchKernelGGL(scale_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(scale_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
 }
 
 }  // extern "C"

@@ -421,7 +421,9 @@ struct MarchAdjAccQ : SiteBase<P> {
 #define PDE_AMD_STAMP(slot) do {} while (0)
 #endif
 
-template <class P, int W>
+// WITH_LOSS: the kernel also leaves the forward's partial sums (sum of weight * R^2 over the tile, frames of this
+// chunk) in a.partial: the residuals are recomputed here anyway, so a training step needs no separate forward launch.
+template <class P, int W, bool WITH_LOSS = false>
 __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bwd_march_q_kernel(const Args a) {
   using C = QuadCfg<P, W>;
   using fv = typename VecOf<W>::type;
@@ -459,6 +461,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   __shared__ __attribute__((aligned(16))) float s_g[P::NE * TG::SIZE];
   float* const s_f = s_fpad + C::LDS_PAD;
   __shared__ __attribute__((aligned(16))) float s_x[AUX_ON ? P::NA * TX::SIZE : 4];
+  __shared__ double s_red[WITH_LOSS ? (NT / 64) * P::NE : 1];
 
   const Geom& g = a.geo;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -511,6 +514,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   // region quads of this thread (tile plus the adjoint's reach, x reach rounded up to whole quads)
   int rF[RPT], rG[RPT], rX[RPT], r0[RPT], r1[RPT], r2[RPT];
   bool rrow[RPT], rfull[RPT];      // rfull: wave-uniform, every point of every active lane's quad lies on the lattice
+  bool rint[RPT];                  // the quad belongs to the tile itself and to the grid: its residuals count for the loss
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int iraw = (ALT && j == RPT - 1 ? (int)threadIdx.x % (NT / 2) : (int)threadIdx.x) + j * NT;
@@ -524,6 +528,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
     r0[j] = c0; r1[j] = c1; r2[j] = c2;
     rrow[j] = ok && c0 >= g.lo0 && c0 < g.N0 - g.hi0 && c1 >= g.lo1 && c1 < g.N1 - g.hi1;
     rfull[j] = wave_all(iraw >= NRQ || (rrow[j] && c2 >= g.lo2 && c2 + W - 1 < g.N2 - g.hi2));
+    rint[j] = iraw < NRQ && l0 >= 0 && l0 < TG::T0 && l1 >= 0 && l1 < TG::T1 && l2 >= 0 && l2 < TG::T2 &&
+              o0 + l0 < g.N0 && o1 + l1 < g.N1 && o2 + l2 < g.N2;
     rG[j] = W * i;
     rF[j] = TF::at(l0, l1, l2);
     rX[j] = TX::at(l0, l1, l2);
@@ -570,6 +576,9 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + min(max(n0 - 1, 0), g.TR - 1));
+  double lsum[P::NE];
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) lsum[k] = 0.0;
 
   // Frames are fetched two steps before the step that needs them in LDS: the loads of frame n+3 are issued
   // at the top of step n into one of two register sets and written to the ring at the end of step n+1, so a
@@ -603,9 +612,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 
     // G(n) = coef * R(n) on the tile plus the adjoint's reach
     const bool gvalid = n >= na && n <= nb;
-    float cf[P::NE];
+    float cf[P::NE], wl[P::NE];
+    const bool lvalid = WITH_LOSS && gvalid && n >= qa && n < qb;      // every residual frame counts in exactly one chunk
 #pragma unroll
     for (int k = 0; k < P::NE; ++k) {
+      wl[k] = lvalid ? wnext[k] : 0.0f;
       cf[k] = to_vgpr(gvalid ? up[k] * wnext[k] : 0.0f);
       wnext[k] = ldc(a.wt, k * g.TR + min(max(n, 0), g.TR - 1));
     }
@@ -634,7 +645,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
             float R[P::NE];
             P::residual(racc, R);
 #pragma unroll
-            for (int k = 0; k < P::NE; ++k) Gq[k][px] = cf[k] * R[k];
+            for (int k = 0; k < P::NE; ++k) Gq[k][px] = WITH_LOSS ? R[k] : cf[k] * R[k];
           }
           if (!rfull[j]) {      // off-lattice points carry no residual
 #pragma unroll
@@ -644,6 +655,19 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 #pragma unroll
               for (int k = 0; k < P::NE; ++k) Gq[k][px] = ok ? Gq[k][px] : 0.0f;
             }
+          }
+          if (WITH_LOSS) {      // Gq holds the residuals: their squares first, then the scaled residuals
+            if (rint[j]) {
+#pragma unroll
+              for (int k = 0; k < P::NE; ++k) {
+                float part = 0.0f;
+#pragma unroll
+                for (int px = 0; px < W; ++px) part += Gq[k][px] * Gq[k][px];
+                lsum[k] += (double)part * (double)wl[k];
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < P::NE; ++k) Gq[k] = Gq[k] * cf[k];
           }
         }
 #pragma unroll
@@ -750,6 +774,10 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   for (int n = n0; n <= qb; n += 2) {
     step(n, 0, stage_a, stage_b);
     step(n + 1, 1, stage_b, stage_a);      // without DEEP the sets are independent scratch and one of them is optimised away
+  }
+  if (WITH_LOSS) {
+    __syncthreads();
+    block_sum_store<P::NE, NT>(lsum, s_red, a.partial + (long)w * P::NE);
   }
 }
 

@@ -147,6 +147,47 @@ class HipBackend:
         return grads
 
 
+    def forward_backward(self, prob: StencilProblem, fields, aux, sparams, weights, assumed: torch.Tensor):
+        """One pass: (totals, sums, gradients of assumed * totals[-1]).  `assumed` is a device scalar."""
+        f0 = fields[0]
+        if not f0.is_cuda:
+            raise RuntimeError("pde_amd: fields must be on a HIP device (there is no CPU fallback)")
+        L = _lib.lib()
+        s = SPECS[prob.spec]
+        cp = prob.c_struct(f0.shape)
+        ne = len(s.eqs)
+        sums = torch.empty((f0.shape[0], ne), dtype=torch.float64, device=f0.device)
+        totals = torch.empty((ne + 1,), dtype=torch.float32, device=f0.device)
+        grads = [torch.empty_like(f) for f in fields]
+        ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
+        ws = self._workspace(f0.device, ws_bytes)
+        ev = None
+        if self.backward_events is not None:      # the adjoint kernel does the whole step here
+            ev = self.backward_event_pool.pop() if self.backward_event_pool else (
+                torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        with self._on(f0.device):
+            st = L.pde_amd_residual_forward_backward(
+                C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
+                _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), C.c_void_p(assumed.data_ptr()),
+                C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), _lib.ptr_array(grads, len(grads)),
+                C.c_void_p(ws.data_ptr()), ws_bytes, self._stream(f0))
+        if ev is not None:
+            ev[1].record()
+            self.backward_events.append(ev)
+        _lib.check(st, f"residual_forward_backward[{prob.spec}]")
+        return totals, sums, grads
+
+    def rescale(self, grads, upstream: torch.Tensor, assumed: torch.Tensor):
+        """grads *= upstream / assumed in place; a no-op decided on the device when the two scalars are equal."""
+        g0 = grads[0]
+        with self._on(g0.device):
+            st = _lib.lib().pde_amd_rescale_gradients(_lib.ptr_array(grads, len(grads)), len(grads), g0.numel(),
+                                                      C.c_void_p(upstream.data_ptr()), C.c_void_p(assumed.data_ptr()),
+                                                      self._stream(g0))
+        _lib.check(st, "rescale_gradients")
+
+
 _BACKEND = HipBackend()
 
 
@@ -167,10 +208,22 @@ class _ResidualLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, aux, sparams, weights, mode, *fields):
         need_grad = any(ctx.needs_input_grad[5:])
+        assumed = None
+        if isinstance(mode, tuple):      # ('fused', device scalar): the upstream gradient of the total to assume
+            mode, assumed = mode
+        if mode == "fused" and not _BACKEND.can_recompute(prob.spec):
+            mode = "stored"
         if mode == "auto":
             mode = "recompute" if _BACKEND.can_recompute(prob.spec) else "stored"
-        store = need_grad and mode == "stored"
-        totals, sums, resid = _BACKEND.forward(prob, fields, aux, sparams, weights, store)
+        ctx.ghat = ctx.assumed = None
+        if need_grad and mode == "fused":
+            # loss and gradient in one pass; the gradient is handed out in backward, rescaled if autograd delivers
+            # another upstream value than the assumed one
+            totals, sums, ctx.ghat = _BACKEND.forward_backward(prob, fields, aux, sparams, weights, assumed)
+            ctx.assumed, resid = assumed, None
+        else:
+            store = need_grad and mode == "stored"
+            totals, sums, resid = _BACKEND.forward(prob, fields, aux, sparams, weights, store)
         ctx.prob, ctx.aux, ctx.sparams, ctx.weights, ctx.resid = prob, aux, sparams, weights, resid
         ctx.save_for_backward(*fields)
         ctx.set_materialize_grads(False)
@@ -186,7 +239,13 @@ class _ResidualLosses(torch.autograd.Function):
         gs = gsums.to(torch.float64).contiguous() if gsums is not None else None
         if ups is None and gs is None:
             return (None,) * (5 + len(fields))
-        grads = _BACKEND.backward(ctx.prob, fields, ctx.aux, ctx.sparams, ctx.weights, ups, gs, ctx.resid)
+        ghat, ctx.ghat = ctx.ghat, None      # handed out once; a second backward recomputes
+        if ghat is not None and gs is None and ups[-1] is not None and all(u is None for u in ups[:-1]):
+            _BACKEND.rescale(ghat, ups[-1], ctx.assumed)
+            grads = ghat
+        else:
+            del ghat
+            grads = _BACKEND.backward(ctx.prob, fields, ctx.aux, ctx.sparams, ctx.weights, ups, gs, ctx.resid)
         out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[5:])]
         return (None, None, None, None, None, *out)
 
@@ -198,7 +257,9 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
 
     loss_k = sum_{b, t, site} weights[k, t] * R_k(b, t, site)^2.
     mode: 'recompute' (adjoint kernel re-evaluates the residuals; nothing is stored between forward and
-    backward), 'stored' (forward writes the residuals, backward reads them), or 'auto'.
+    backward), 'stored' (forward writes the residuals, backward reads them), 'auto', or ('fused', assumed): loss and
+    gradient of assumed * total in one pass at forward time when the fields need gradients (`assumed` is a device
+    scalar); backward hands the gradient out, rescaled on the device if the upstream value differs.
     """
     s = SPECS[prob.spec]
     if len(fields) != len(s.fields) or len(sparams) != len(s.sparams) or len(aux) != len(s.aux):

@@ -34,7 +34,12 @@ class StencilPDELoss(nn.Module):
     PER_T_ALIAS: Dict[str, str] = {}        # equation -> buffer suffix when they differ
     TOTAL_KEY: bool = False                 # whether the dict carries 'total'
     SCALE_KEYS: Dict[str, str] = {}         # equation -> key looked up in eq_scales / eq_weights when they differ
-    backward_mode = "auto"                  # 'recompute' | 'stored' | 'auto' (recompute where the PDE supports it)
+    backward_mode = "auto"                  # 'recompute' | 'stored' | 'fused' | 'auto' (recompute where the PDE supports it)
+    # 'fused': when the fields need gradients, forward computes the loss AND the gradient of upstream_hint * total in
+    # one pass (the adjoint kernel recomputes every residual anyway); backward hands that gradient out.  If autograd
+    # then delivers another upstream value (lambda_pde, a loss scaler) the gradient is rescaled on the device, one more
+    # pass over it: set upstream_hint to the factor the training loop applies to `total`.  No host synchronisation.
+    upstream_hint = 1.0
 
     def _init_common(self, default_scales, eq_scales, eq_weights, eq_scales_per_t, per_t_supported=True):
         self.eq_scales = {**default_scales, **(eq_scales or {})}
@@ -145,7 +150,11 @@ class StencilPDELoss(nn.Module):
         T_res = T - spec.tlo - spec.thi
         n_sites = B * max(T_res, 0) * ext[0] * ext[1] * ext[2]
         wt, skipped = self._weights(T_res, n_sites, f0.device, t_offset)
-        totals, sums = residual_losses(prob, fields, wt, sparams, aux, mode=self.backward_mode)
+        mode = self.backward_mode
+        if mode == "fused":
+            hint = float(self.upstream_hint)
+            mode = ("fused", self._buf(("assumed", hint), lambda: torch.tensor(hint, dtype=torch.float32), f0.device))
+        totals, sums = residual_losses(prob, fields, wt, sparams, aux, mode=mode)
         self.last_per_sample = sums.detach()        # [B, n_eqs] fp64 diagnostic: each sample's share of every loss
         losses: Dict[str, Tensor] = {}
         all_kept = not any(skipped) and n_sites > 0
@@ -161,6 +170,12 @@ class StencilPDELoss(nn.Module):
         if self.TOTAL_KEY:
             losses["total"] = total
         return total, losses
+
+    def _buf(self, name, make, device):
+        key = (name, str(device))
+        if key not in self._wt_cache:
+            self._wt_cache[key] = make().to(device)
+        return self._wt_cache[key]
 
     def _zero(self, device) -> Tensor:
         key = ("zero", str(device))
@@ -610,12 +625,6 @@ class GrayScottPDELoss(StencilPDELoss):
         nk = self.K2.shape[1] // 2 + 1
         negK2 = self._buf("negK2h", lambda: -self.K2[:, :nk].contiguous(), f.device)
         return torch.fft.irfft2(negK2 * torch.fft.rfft2(f), s=f.shape[-2:])
-
-    def _buf(self, name, make, device):
-        key = (name, str(device))
-        if key not in self._wt_cache:
-            self._wt_cache[key] = make().to(device)
-        return self._wt_cache[key]
 
     def forward(self, A: Tensor, B: Tensor, reduction: str = "mean"):
         if reduction != "mean":

@@ -187,3 +187,14 @@ class InterpBackend:
                 g = np.broadcast_to(env.ev(e), env.shape) * 1.0
                 out.append(torch.tensor(g.reshape(fields[f].shape), dtype=torch.float32, device=fields[f].device))
         return out
+
+    def forward_backward(self, prob, fields, aux, sparams, weights, assumed):
+        totals, sums, _ = self.forward(prob, fields, aux, sparams, weights, False)
+        ups = [None] * len(SPECS[prob.spec].eqs) + [assumed]
+        return totals, sums, self.backward(prob, fields, aux, sparams, weights, ups, None, None)
+
+    def rescale(self, grads, upstream, assumed):
+        r = float(upstream) / float(assumed)
+        if r != 1.0:
+            for g in grads:
+                g.mul_(r)

@@ -98,7 +98,7 @@ def _quad_variant(entry):
 SIZED = SIZED + [_quad_variant(e) for e in SIZED]
 
 
-@pytest.mark.parametrize("mode", ["auto", "stored"])
+@pytest.mark.parametrize("mode", ["auto", "stored", "fused"])
 @pytest.mark.parametrize("cls,kw,shape,ps", SIZED, ids=[f"{s[0]}-{s[2][-1]}" for s in SIZED])
 def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
     dev = _dev()
@@ -120,6 +120,45 @@ def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
         assert abs(float(losses[k]) - float(ol[k])) <= TOL * abs(float(ol[k])) + 1e-30, k
     for gr, f in zip(grads, f64):
         assert rel_l2(gr.cpu().numpy(), f.grad.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("cls,kw,shape,ps", [SIZED[1], SIZED[len(SIZED) // 2 + 1], SIZED[len(SIZED) // 2 + 2], SIZED[len(SIZED) // 2 + 3]],
+                         ids=["tg2d-ragged", "tg2d-quad", "shear-quad", "rb-quad"])
+def test_fused_mode_upstream_values(cls, kw, shape, ps):
+    """fused mode against the default mode: assumed upstream hit or missed, a per-equation upstream and a second
+    backward (both take the ordinary adjoint), gradients wanted for some fields only"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    nf = len(PL.SPECS[getattr(PL, cls).SPEC].fields)
+    fields = [(torch.randn(shape, generator=g) * 0.5).to(dev) for _ in range(nf)]
+    extra = {k: (lo + (hi - lo) * torch.rand(shape[0], generator=g)).to(dev) for k, (lo, hi) in ps.items()}
+
+    def run(mode, hint, use, need=None):
+        mod = getattr(PL, cls)(**kw).to(dev)
+        mod.backward_mode, mod.upstream_hint = mode, hint
+        fs = [f.clone().requires_grad_(need is None or i in need) for i, f in enumerate(fields)]
+        total, losses = mod(*fs, **extra)
+        obj = use(total, losses)
+        obj.backward(retain_graph=True)
+        g1 = [None if f.grad is None else f.grad.clone() for f in fs]
+        for f in fs:
+            f.grad = None
+        obj.backward()
+        return total.detach(), g1, [None if f.grad is None else f.grad.clone() for f in fs]
+
+    first_eq = getattr(PL, cls).EQS[0]
+    uses = [lambda t, l: t, lambda t, l: 0.37 * t, lambda t, l: 2.0 * l[first_eq] + t]
+    for use in uses:
+        t0, ga, _ = run("auto", 1.0, use)
+        for hint in (1.0, 0.37):
+            t1, g1, g2 = run("fused", hint, use)
+            assert abs(float(t1) - float(t0)) <= 1e-6 * abs(float(t0))
+            for a, b, c in zip(ga, g1, g2):
+                assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) <= 1e-6
+                assert rel_l2(c.cpu().numpy(), a.cpu().numpy()) <= 1e-6
+    t0, ga, _ = run("auto", 1.0, uses[0], need={0})
+    t1, g1, _ = run("fused", 1.0, uses[0], need={0})
+    assert g1[1] is None and rel_l2(g1[0].cpu().numpy(), ga[0].cpu().numpy()) <= 1e-6
 
 
 def test_no_grad_and_partial_requires_grad():

@@ -107,3 +107,35 @@ def test_gray_scott_fd4_matches_oracle():
     assert abs(float(total) - float(ot)) <= 3e-6 * abs(float(ot))
     assert rel_l2(grads[0].numpy(), a64.grad.numpy()) <= 3e-6
     assert rel_l2(grads[1].numpy(), b64.grad.numpy()) <= 3e-6
+
+
+def test_fused_mode_host_logic():
+    """backward_mode='fused': same loss and gradients as the default mode, for the assumed upstream value, another one,
+    a per-equation upstream (falls back to the ordinary adjoint) and a second backward through the same graph"""
+    import pde_amd
+    gen = torch.Generator().manual_seed(3)
+    fields0 = [torch.randn(2, 5, 8, 8, generator=gen) for _ in range(3)]
+    nu = torch.tensor([0.02, 0.05])
+
+    def run(mode, hint, use):
+        fn = pde_amd.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01)
+        fn.backward_mode, fn.upstream_hint = mode, hint
+        fs = [f.clone().requires_grad_(True) for f in fields0]
+        total, losses = fn(*fs, nu=nu)
+        obj = use(total, losses)
+        obj.backward(retain_graph=True)
+        g1 = [f.grad.clone() for f in fs]
+        for f in fs:
+            f.grad = None
+        obj.backward()
+        return float(total), g1, [f.grad.clone() for f in fs]
+
+    uses = [lambda t, l: t, lambda t, l: 0.37 * t, lambda t, l: 2.0 * l["x_momentum"] + t]
+    for use in uses:
+        t0, ga, gb = run("auto", 1.0, use)
+        for hint in (1.0, 0.37):
+            t1, g1, g2 = run("fused", hint, use)
+            assert t1 == t0
+            for a, b, c in zip(ga, g1, g2):
+                assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+                assert float((a - c).abs().max()) <= 1e-6 * float(a.abs().max())

@@ -2,4 +2,4 @@
 import json, sys
 d = json.loads(sys.stdin.readlines()[-1])
 r = d["roofline"]
-print("ms/step %.4f  bwd %.4f (avg %.4f)  fwd %.4f" % (d["ms_per_step"], r["median_ms"], r["avg_ms"], r["fwd_median_ms"]))
+print("ms/step %.4f  bwd %.4f (avg %.4f)  fwd %.4f" % (d["ms_per_step"], r["median_ms"], r["avg_ms"], r.get("fwd_median_ms", float("nan"))))
