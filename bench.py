@@ -220,7 +220,7 @@ def main():
                                                      "on the launch stream around it" + ("; in fused mode it also sums the loss, and the "
                                                      "events include the small reduction kernel that follows)" if args.mode == "fused" else ")"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("bwd_march_q_kernel"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
+                         "traffic": measured_traffic("bwd_march_q_kernel<pde_amd::Pde_tg2d, 4, true>" if args.mode == "fused" else "bwd_march_q_kernel<pde_amd::Pde_tg2d, 4>"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
                          "median_ms": k_ms[len(k_ms) // 2], "timed_launches": len(k_ms),
                          **({"fwd_median_ms": f_ms[len(f_ms) // 2], "fwd_algorithmic_bytes": 4 * e_in,
                              "fwd_traffic": measured_traffic("fwd_march_q_kernel")} if f_ms else {})},

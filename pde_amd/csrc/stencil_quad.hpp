@@ -612,7 +612,9 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 
     // G(n) = coef * R(n) on the tile plus the adjoint's reach
     const bool gvalid = n >= na && n <= nb;
-    float cf[P::NE], wl[P::NE];
+    float cf[P::NE], wl[P::NE], lpart[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) lpart[k] = 0.0f;
     const bool lvalid = WITH_LOSS && gvalid && n >= qa && n < qb;      // every residual frame counts in exactly one chunk
 #pragma unroll
     for (int k = 0; k < P::NE; ++k) {
@@ -657,14 +659,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
             }
           }
           if (WITH_LOSS) {      // Gq holds the residuals: their squares first, then the scaled residuals
-            if (rint[j]) {
+            if (rint[j]) {      // fp32 over the few points a lane sees in one step, fp64 across steps
 #pragma unroll
-              for (int k = 0; k < P::NE; ++k) {
-                float part = 0.0f;
+              for (int k = 0; k < P::NE; ++k)
 #pragma unroll
-                for (int px = 0; px < W; ++px) part += Gq[k][px] * Gq[k][px];
-                lsum[k] += (double)part * (double)wl[k];
-              }
+                for (int px = 0; px < W; ++px) lpart[k] += Gq[k][px] * Gq[k][px];
             }
 #pragma unroll
             for (int k = 0; k < P::NE; ++k) Gq[k] = Gq[k] * cf[k];
@@ -673,6 +672,10 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) *reinterpret_cast<fv*>(s_g + k * TG::SIZE + rG[j]) = Gq[k];
       }
+    }
+    if (WITH_LOSS) {
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) lsum[k] += (double)lpart[k] * (double)wl[k];
     }
     PDE_AMD_STAMP(2);
     __syncthreads();
