@@ -63,6 +63,7 @@ def train_losses(shared):
     pde, _ = pde_amd.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)
     bc_l = pde_amd.compute_boundary_loss(o, tgt, m2, 1)
     (1e-3 * pde + 0.1 * bc_l).backward()
-for shared in (False, True):
+for shared, mode in ((False, "auto"), (True, "auto"), (True, "fused")):
+    fn.backward_mode, fn.upstream_hint = mode, 1e-3
     ms = timeit(lambda: train_losses(shared))
-    print(f"step losses (gather + TG residual + boundary strips) fwd+bwd, {'one shared gradient buffer' if shared else 'separate gradients added by autograd'}: {ms:.3f} ms")
+    print(f"step losses (gather + TG residual + boundary strips) fwd+bwd, {'one shared gradient buffer' if shared else 'separate gradients added by autograd'}, backward_mode={mode}: {ms:.3f} ms")
