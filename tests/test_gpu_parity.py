@@ -232,3 +232,91 @@ def test_per_sample_sums_are_differentiable():
     (per * coeff.cpu().view(-1)).sum().backward()
     assert rel_l2(ud.grad.cpu().numpy(), u64.grad.numpy()) <= TOL
     assert rel_l2(sums.detach().cpu().numpy().ravel(), per.detach().numpy()) <= TOL
+
+
+def _full_size_properties(mod, fields, extra, shifts, modes=("auto",)):
+    """size-independent checks at benchmark sizes, where no CPU oracle run is affordable:
+    (1) a periodic shift of the fields (x by a multiple of 4, the lane width) shifts the gradients bit-exactly (every site
+        sees the same neighbours, so tiles, halos, wrap-around and chunk ends must not matter) and leaves the per-sample sums unchanged up to summation order;
+    (2) a permutation of the samples permutes per-sample sums and gradients bit-exactly;
+    (3) the gradient matches a central difference of the fp64 per-sample sums along a random direction;
+    (4) every backward mode gives the same numbers."""
+    dims = tuple(range(2, fields[0].dim()))
+
+    def run(fs, ex, mode):
+        mod.backward_mode = mode
+        fs = [f.detach().clone().requires_grad_(True) for f in fs]
+        total, _ = mod(*fs, **ex)
+        total.backward()
+        return total.detach(), mod.last_per_sample.clone(), [f.grad for f in fs]
+
+    t0, s0, g0 = run(fields, extra, modes[0])
+    assert torch.isfinite(t0) and all(torch.isfinite(g).all() for g in g0)
+    for mode in modes[1:]:
+        t1, s1, g1 = run(fields, extra, mode)
+        assert abs(float(t1) - float(t0)) <= 1e-6 * abs(float(t0))
+        for a, b in zip(g0, g1):
+            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), mode
+    # (1)
+    t1, s1, g1 = run([torch.roll(f, shifts, dims) for f in fields], extra, modes[0])
+    assert float(((s1 - s0).abs() / s0.abs().clamp_min(1e-300)).max()) <= 1e-9
+    for a, b in zip(g0, g1):
+        assert torch.equal(torch.roll(a, shifts, dims), b)
+    # an x shift that is not a multiple of the lane width moves a site to another of the lane's points, whose multiply-adds
+    # the compiler may contract differently: same values up to rounding
+    odd = shifts[:-1] + (shifts[-1] + 1,)
+    t1, s1, g1 = run([torch.roll(f, odd, dims) for f in fields], extra, modes[0])
+    for a, b in zip(g0, g1):
+        assert float((torch.roll(a, odd, dims) - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    # (2)
+    B = fields[0].shape[0]
+    if B > 1:
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(fields[0].device)
+        t2, s2, g2 = run([f[perm] for f in fields], {k: v[perm] for k, v in extra.items()}, modes[0])
+        assert torch.equal(s2, s0[perm])
+        for a, b in zip(g0, g2):
+            assert torch.equal(a[perm], b)
+    # (3)
+    gen = torch.Generator(device=fields[0].device).manual_seed(2)
+    d = [torch.randn(f.shape, generator=gen, device=f.device) for f in fields]
+    scale = float(fields[0].abs().mean())
+    eps = 1e-3 * scale
+    with torch.no_grad():
+        mod(*[f + eps * x for f, x in zip(fields, d)], **extra)
+        up = mod.last_per_sample.sum(0)
+        mod(*[f - eps * x for f, x in zip(fields, d)], **extra)
+        dn = mod.last_per_sample.sum(0)
+    fd = float((up - dn).sum() / (2 * eps))
+    an = float(sum((g.double() * x.double()).sum() for g, x in zip(g0, d)))
+    assert abs(fd - an) <= 2e-3 * abs(an), (fd, an)
+
+
+def test_full_size_taylor_green_properties():
+    """BASELINE configuration C2: B=16, T=16, 256 x 256, three fields"""
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(31)
+    fields = [torch.randn(16, 16, 256, 256, generator=gen, device=dev) * 0.5 for _ in range(3)]
+    nu = 0.01 + 0.09 * torch.rand(16, generator=gen, device=dev)
+    mod = PL.TaylorGreen2DPDELoss(nx=256, ny=256, dt=0.01).to(dev)
+    _full_size_properties(mod, fields, dict(nu=nu), (37, 100), modes=("auto", "fused", "stored"))
+    # the analytic Taylor-Green vortex solves the equations: its residual loss is at the fp32 noise floor of the stencils
+    x = torch.arange(256, device=dev, dtype=torch.float64) * (2 * torch.pi / 256)
+    X, Y = x.view(1, 1, 1, 256), x.view(1, 1, 256, 1)
+    t = (torch.arange(16, device=dev, dtype=torch.float64) * 0.01).view(1, 16, 1, 1)
+    dec = torch.exp(-2.0 * nu.double().view(16, 1, 1, 1) * t)
+    u = (torch.sin(X) * torch.cos(Y) * dec).float()
+    v = (-torch.cos(X) * torch.sin(Y) * dec).float()
+    p = (0.25 * (torch.cos(2 * X) + torch.cos(2 * Y)) * dec ** 2).float()
+    with torch.no_grad():
+        exact, _ = mod(u, v, p, nu=nu)
+        noisy, _ = mod(u + 0.01 * fields[0], v, p, nu=nu)
+    assert float(exact) < 1e-4 * float(noisy), (float(exact), float(noisy))
+
+
+def test_full_size_burgers3d_properties():
+    """BASELINE configuration C5: one sample of 128^3, three fields (stored-residual kernels)"""
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(32)
+    fields = [torch.randn(1, 9, 128, 128, 128, generator=gen, device=dev) * 0.5 for _ in range(3)]
+    mod = PL.APEBenchBurgers3DPDELoss(nx=128, Lx=1.0, dt=1.0).to(dev)
+    _full_size_properties(mod, fields, {}, (5, 17, 68))
