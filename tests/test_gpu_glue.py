@@ -139,3 +139,41 @@ def test_cpu_tensor_rejected():
 
 def test_shared_grad():
     GC.check_shared_grad(DEV)
+
+
+def test_full_size_metric_properties():
+    """rollout-evaluation size [64, 512, 128, 18] (no CPU oracle run at this size): the statistics kernel against fp64
+    torch reductions of the same tensors, scale invariance of nRMSE, sample permutation, and the gather/scatter pair as
+    exact adjoints of each other"""
+    import pde_amd
+    from pde_amd import reductions as R
+    gen = torch.Generator(device=DEV).manual_seed(41)
+    M, H, W, C = 64, 512, 128, 18
+    p = torch.randn(M, H, W, C, generator=gen, device=DEV)
+    g = torch.randn(M, H, W, C, generator=gen, device=DEV) * 0.7 + 0.1
+    st = R.get_backend().pair_stats(p, g, M, H * W, C)                     # [M, C, 6] fp64
+    d = (p.double() - g.double())
+    want_d2 = (d * d).sum(dim=(1, 2))
+    want_g2 = (g.double() ** 2).sum(dim=(1, 2))
+    assert float(((st[:, :, R.S_D2] - want_d2).abs() / want_d2).max()) <= 1e-7      # the kernel subtracts in fp32, like the reference
+    assert float(((st[:, :, R.S_G2] - want_g2).abs() / want_g2).max()) <= 1e-7
+    assert torch.equal(st[:, :, R.S_MAXD].float(), (p - g).abs().amax(dim=(1, 2)))
+    names = [(0, "vx"), (1, "vy"), (15, "p")]
+    a = pde_amd.nrmse_per_channel(p, g, names)
+    b = pde_amd.nrmse_per_channel(3.0 * p, 3.0 * g, names)                 # scale invariance
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(2)).to(DEV)
+    c = pde_amd.nrmse_per_channel(p[perm], g[perm], names)
+    for _, n in names:
+        assert float(((a[n] - b[n]).abs() / a[n]).max()) <= 1e-6
+        assert torch.equal(a[n][perm], c[n])
+    # <gather(x), y> == <x, scatter(y)> on the trainer layout [B, T, H, W, C]
+    out = torch.randn(4, 5, 256, 256, C, generator=gen, device=DEV, requires_grad=True)
+    inp = torch.randn(4, 2, 256, 256, C, generator=gen, device=DEV)
+    fields = pde_amd.gather_fields(out, inp, (0, 1, 15))
+    ys = [torch.randn(f.shape, generator=gen, device=DEV) for f in fields]
+    sum((f * y).sum() for f, y in zip(fields, ys)).backward()
+    for ci, (f, y) in zip((0, 1, 15), zip(fields, ys)):
+        assert torch.equal(f[:, 1:], out.detach()[..., ci]) and torch.equal(f[:, 0], inp[:, 0, ..., ci])
+        assert torch.equal(out.grad[..., ci], y[:, 1:])
+    others = [c for c in range(C) if c not in (0, 1, 15)]
+    assert float(out.grad[..., others].abs().max()) == 0.0
