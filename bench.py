@@ -203,7 +203,7 @@ def main():
     if rank == 0:
         k_ms = sorted(x.elapsed_time(y) for x, y in bwd_events)
         f_ms = sorted(x.elapsed_time(y) for x, y in fwd_events)      # empty in fused mode: there is no forward launch
-        bwd_avg = sum(k_ms) / len(k_ms)                   # the adjoint kernel launch (fused mode: plus the 4 us reduction of the loss partials)
+        bwd_avg = sum(k_ms) / len(k_ms)                   # the adjoint kernel launch alone
         e_in = 3 * B * T * H * W
         bwd_bytes = 8 * e_in            # adjoint: read every field once, write every gradient once
         achieved = bwd_bytes / (bwd_avg * 1e-3) / 1e9
@@ -216,9 +216,9 @@ def main():
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank,
                        "launch": "hip-graph replay, every 5th step eager with kernel events" if graph is not None else "eager",
                        "backward_mode": args.mode},
-            "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step, HIP events "
-                                                     "on the launch stream around it" + ("; in fused mode it also sums the loss, and the "
-                                                     "events include the small reduction kernel that follows)" if args.mode == "fused" else ")"),
+            "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step; HIP events recorded by "
+                                                     "the library on the launch stream right before and after that launch" +
+                                                     ("; in fused mode the kernel also sums the loss)" if args.mode == "fused" else ")"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("bwd_march_q_kernel<pde_amd::Pde_tg2d, 4, true>" if args.mode == "fused" else "bwd_march_q_kernel<pde_amd::Pde_tg2d, 4>"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
                          "median_ms": k_ms[len(k_ms) // 2], "timed_launches": len(k_ms),

@@ -103,6 +103,13 @@ int pde_amd_residual_forward_backward(const pde_amd_problem* prob,
                                       const float* upstream_total, double* sums, float* totals,
                                       float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement hook, no counterpart in the reference: the next launch of the register-blocked adjoint kernel issued from
+ * this host thread (by pde_amd_residual_backward in recompute mode or by pde_amd_residual_forward_backward) records the
+ * two HIP events (hipEvent_t, created with timing enabled) on its stream immediately before and after that one launch;
+ * the small reduction launches of the same call stay outside.  One-shot: the events are forgotten afterwards, also when
+ * the call took another kernel.  NULL, NULL disarms it. */
+int pde_amd_time_next_adjoint(void* start_event, void* stop_event);
+
 /* grads[f][i] *= *upstream / *assumed for n_fields arrays of `elements` floats; nothing is read or written when the
  * two device scalars are equal (decided on the device, no host synchronisation).  It turns the gradients that
  * pde_amd_residual_forward_backward produced for an assumed upstream value into those for the value autograd

@@ -45,6 +45,19 @@ __global__ __launch_bounds__(256) void scale_kernel(const ScaleArgs a) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// One-shot timing hook (pde_amd_time_next_adjoint): the next launch of the vector adjoint kernel on this host thread is
+// bracketed by these two events on its own stream, nothing else of the call is.
+static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+struct AdjointTimer {
+  hipStream_t st;
+  hipEvent_t e1;
+  explicit AdjointTimer(hipStream_t s) : st(s), e1(t_ev1) {
+    if (t_ev0) (void)hipEventRecord(t_ev0, st);
+    t_ev0 = t_ev1 = nullptr;
+  }
+  ~AdjointTimer() { if (e1) (void)hipEventRecord(e1, st); }
+};
+
 // The register-blocked kernels move 16 bytes per lane: every pointer must be 16-byte aligned and the
 // fastest extent a multiple of 4.
 template <int N, int W>
@@ -247,7 +260,10 @@ struct Ops {
         const long items = (long)cdiv(p->frames, a.chunk) * qtiles;
         const long nwg = (long)p->batch * items;
         if (nwg < (1L << 31) && (size_t)nwg * P::NE * sizeof(double) <= ws_bytes_given) {
-          hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
+          {
+            AdjointTimer timer(stream);
+            hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
+          }
           reduce_partials(a.partial, sums, totals, items, p->batch, stream);
           fused = true;
         }
@@ -324,6 +340,7 @@ struct Ops {
 #else
         constexpr int dyn_lds = 0;
 #endif
+        AdjointTimer timer(stream);
         hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
       }
     } else {
@@ -430,6 +447,12 @@ int pde_amd_residual_forward_backward(const pde_amd_problem* prob, const float* 
   if (!v) return PDE_AMD_EINVAL;
   return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+int pde_amd_time_next_adjoint(void* start_event, void* stop_event) {
+  t_ev0 = static_cast<hipEvent_t>(start_event);
+  t_ev1 = static_cast<hipEvent_t>(stop_event);
+  return PDE_AMD_OK;
 }
 
 int pde_amd_rescale_gradients(float* const* grads, int32_t n_fields, int64_t elements, const float* upstream,

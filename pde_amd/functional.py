@@ -57,7 +57,7 @@ class HipBackend:
 
     name = "hip"
     # Optional instrumentation: when set to a list, every backward launch appends a (start, end) pair of events recorded
-    # on the launch stream right around the C call, so a benchmark can time the adjoint kernel alone.
+    # on the launch stream by the library itself, right around its adjoint kernel launch (pde_amd_time_next_adjoint).
     backward_events = None
     backward_event_pool = None       # optional list of pre-created (start, end) event pairs to draw from
     forward_events = None            # same for the forward launches (residual kernel + the two tiny reductions)
@@ -83,6 +83,23 @@ class HipBackend:
     def _on(device):
         """Context that makes `device` current for the launch; free when it already is."""
         return contextlib.nullcontext() if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def _arm_adjoint_timer(self):
+        """With backward_events set: a pair of events that the library records right around its next adjoint kernel launch."""
+        if self.backward_events is None:
+            return None
+        ev = self.backward_event_pool.pop() if self.backward_event_pool else (
+            torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for e in ev:
+            if not e.cuda_event:      # the handle exists only after a first record
+                e.record()
+        _lib.lib().pde_amd_time_next_adjoint(C.c_void_p(ev[0].cuda_event), C.c_void_p(ev[1].cuda_event))
+        return ev
+
+    def _disarm_adjoint_timer(self, ev):
+        if ev is not None:
+            _lib.lib().pde_amd_time_next_adjoint(None, None)
+            self.backward_events.append(ev)
 
     def can_recompute(self, spec: str) -> bool:
         return bool(_lib.pde_info(spec).can_recompute)
@@ -131,18 +148,12 @@ class HipBackend:
         rptr = _lib.ptr_array(resid, len(resid)) if resid is not None else None
         uptr = _lib.ptr_array(upstream, len(s.eqs) + 1) if upstream is not None else None
         gs = C.c_void_p(upstream_sums.data_ptr()) if upstream_sums is not None else None
-        ev = None
-        if self.backward_events is not None:
-            ev = self.backward_event_pool.pop() if self.backward_event_pool else (
-                torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        ev = self._arm_adjoint_timer()
         with self._on(f0.device):
             st = L.pde_amd_residual_backward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                              _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), uptr, gs,
                                              rptr, _lib.ptr_array(grads, len(grads)), None, 0, self._stream(f0))
-        if ev is not None:
-            ev[1].record()
-            self.backward_events.append(ev)
+        self._disarm_adjoint_timer(ev)
         _lib.check(st, f"residual_backward[{prob.spec}]")
         return grads
 
@@ -161,20 +172,14 @@ class HipBackend:
         grads = [torch.empty_like(f) for f in fields]
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
-        ev = None
-        if self.backward_events is not None:      # the adjoint kernel does the whole step here
-            ev = self.backward_event_pool.pop() if self.backward_event_pool else (
-                torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        ev = self._arm_adjoint_timer()      # the adjoint kernel does the whole step here
         with self._on(f0.device):
             st = L.pde_amd_residual_forward_backward(
                 C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                 _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), C.c_void_p(assumed.data_ptr()),
                 C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), _lib.ptr_array(grads, len(grads)),
                 C.c_void_p(ws.data_ptr()), ws_bytes, self._stream(f0))
-        if ev is not None:
-            ev[1].record()
-            self.backward_events.append(ev)
+        self._disarm_adjoint_timer(ev)
         _lib.check(st, f"residual_forward_backward[{prob.spec}]")
         return totals, sums, grads
 
