@@ -213,6 +213,8 @@ class _ResidualLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, aux, sparams, weights, mode, *fields):
         need_grad = any(ctx.needs_input_grad[5:])
+        if isinstance(mode, tuple) and mode[0] == "nograd":      # called under torch.no_grad(): nothing to prepare for a backward
+            need_grad, mode = False, mode[1]
         assumed = None
         if isinstance(mode, tuple):      # ('fused', device scalar): the upstream gradient of the total to assume
             mode, assumed = mode
@@ -284,5 +286,7 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
         if tuple(x.shape) != (shape[0],) + tuple(shape[2:]):
             raise ValueError(f"{prob.spec}: auxiliary fields must be [B, *spatial], got {tuple(x.shape)}")
     w = weights.to(device=fs[0].device, dtype=torch.float32).contiguous()
+    if not torch.is_grad_enabled():      # inside Function.forward the grad mode is always off, so it is passed in
+        mode = ("nograd", mode)
     out = _ResidualLosses.apply(prob, tuple(ax), tuple(sp), w, mode, *fs)
     return list(out[:-1]), out[-1]

@@ -175,6 +175,22 @@ def test_no_grad_and_partial_requires_grad():
     assert u.grad is not None and v.grad is None
     # frames 0 and T-1 only receive the time-difference contribution
     assert torch.isfinite(u.grad).all()
+    # validation under no_grad on tensors that require gradients: no residuals stored, no adjoint launched
+    from pde_amd import functional as PF
+    be = PF.get_backend()
+    calls = []
+    orig_fb, orig_f = be.forward_backward, be.forward
+    be.forward_backward = lambda *a, **k: calls.append("fb") or orig_fb(*a, **k)
+    be.forward = lambda prob, fields, aux, sp, w, store: calls.append(("f", store)) or orig_f(prob, fields, aux, sp, w, store)
+    try:
+        for mode in ("fused", "stored"):
+            mod.backward_mode = mode
+            with torch.no_grad():
+                t2, _ = mod(u, v, p, nu=torch.tensor([0.02, 0.05], device=dev))
+            assert torch.allclose(t0, t2)
+    finally:
+        be.forward_backward, be.forward = orig_fb, orig_f
+    assert calls == [("f", False), ("f", False)]
 
 
 def test_cpu_tensors_are_rejected():

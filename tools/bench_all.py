@@ -69,6 +69,8 @@ def main():
         except TypeError as e:
             print(f"{tag:28s} ctor failed: {e}")
             continue
+        if "--fused" in sys.argv:
+            mod.backward_mode = "fused"
         fwd_params = inspect.signature(mod.forward).parameters
         nf = sum(1 for q in fwd_params.values() if q.default is inspect.Parameter.empty and q.name not in pk_names(params))
         gen = torch.Generator(device=dev).manual_seed(1)
