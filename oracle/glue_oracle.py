@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 
@@ -185,3 +186,38 @@ def metric_func(pred, target, if_mean=True, Lx=1.0, Ly=1.0, Lz=1.0, iLow=4, iHig
     band = torch.stack([F[:, :iLow].mean(1), F[:, iLow:iHigh].mean(1), F[:, iHigh:].mean(1)], dim=1)
     res = (rmse, nrmse, csv, mx, bd, band, mpp)
     return tuple(r.mean(dim=[0, -1]) for r in res) if if_mean else res
+
+
+def pdebench_nrmse(pred, target):
+    """eval/eval_omni.py:243-278 — per channel sqrt(mean(((p - g) / (std(g) + 1e-8))^2)), std over everything (unbiased);
+    returns (mean over channels, list)."""
+    per = []
+    for c in range(pred.shape[-1]):
+        p, g = pred[..., c], target[..., c]
+        sigma = g.std() + 1e-8
+        per.append(float(torch.sqrt(torch.mean(((p - g) / sigma) ** 2))))
+    return float(np.mean(per)), per
+
+
+def lp_loss(x, y, p=2, reduction="mean", eps=1e-20):
+    """eval/metrics.py:599-623 — per example ||x - y||_p / (eps + ||y||_p) over everything but axis 0."""
+    n = x.shape[0]
+    d = torch.norm(x.reshape(n, -1) - y.reshape(n, -1), p, 1)
+    r = d / (eps + torch.norm(y.reshape(n, -1), p, 1))
+    return r.mean() if reduction == "mean" else r.sum() if reduction == "sum" else r
+
+
+def fft_lp_loss(x, y, p=2, reduction="mean", flow=None, fhigh=None, eps=1e-20):
+    """eval/metrics.py:626-678 — the same ratio on the n-dimensional Fourier coefficients, optionally on the band
+    flow <= k < fhigh of every transformed axis."""
+    n = x.shape[0]
+    dims = list(range(1, x.dim()))
+    xf, yf = torch.fft.fftn(x, dim=dims), torch.fft.fftn(y, dim=dims)
+    lo = 0 if flow is None else flow
+    hi = max(xf.shape[1:]) if fhigh is None else fhigh
+    if 1 <= len(dims) <= 4:
+        sl = (slice(None),) + (slice(lo, hi),) * len(dims)
+        xf, yf = xf[sl], yf[sl]
+    d = torch.norm((xf - yf).reshape(n, -1), p, 1)
+    r = d / (eps + torch.norm(yf.reshape(n, -1), p, 1))
+    return r.mean() if reduction == "mean" else r.sum() if reduction == "sum" else r

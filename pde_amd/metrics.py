@@ -9,6 +9,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import reductions as R
@@ -57,6 +58,70 @@ def nrmse_per_channel(pred, gt, valid_channels_: Sequence[Tuple[int, str]]) -> D
     M, rows, C = _flat(pred, gt, 1)
     st = R.get_backend().pair_stats(pred, gt, M, rows, C)
     return {name: torch.sqrt(st[:, ci, R.S_D2] / (st[:, ci, R.S_G2] + 1e-12)).to(torch.float32) for ci, name in valid_channels_}
+
+
+def compute_pdebench_nrmse(pred, target) -> Tuple[float, List[float]]:
+    """eval/eval_omni.py:243-278 — per channel sqrt(mean(((p - g) / (std(g) + 1e-8))^2)) with the unbiased std of the whole
+    target channel; returns (mean over channels, per-channel list) as Python floats, from ONE pass over the two tensors
+    and one host read (the reference takes a `.item()` per channel)."""
+    G, rows, C = _flat(pred, target, 0)
+    st = R.get_backend().pair_stats(pred, target, 1, rows, C)[0]            # [C, NSTAT] fp64
+    n = float(rows)
+    var = (st[:, R.S_G2] - st[:, R.S_G] * st[:, R.S_G] / n) / (n - 1.0)
+    sigma = torch.sqrt(var.clamp_min(0.0)) + 1e-8
+    per = (torch.sqrt(st[:, R.S_D2] / n) / sigma).tolist()
+    return float(np.mean(per)), [float(v) for v in per]
+
+
+class LpLoss:
+    """eval/metrics.py:599-623 — relative Lp error per example, ||x - y||_p / (eps + ||y||_p) over everything but axis 0.
+    p = 2 is one pass of the statistics kernel over both tensors; other p use device-side torch reductions."""
+
+    def __init__(self, p=2, reduction="mean"):
+        assert p > 0
+        self.p, self.reduction = p, reduction
+
+    def _reduce(self, r):
+        if self.reduction in ["mean"]:
+            return torch.mean(r)
+        if self.reduction in ["sum"]:
+            return torch.sum(r)
+        return r
+
+    def _ratio(self, x, y, eps):
+        n = x.size()[0]
+        if self.p == 2 and x.dtype == y.dtype and x.dtype in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+            rows = x.numel() // max(n, 1)
+            st = R.get_backend().pair_stats(x.reshape(n, rows, 1), y.reshape(n, rows, 1), n, rows, 1)
+            return (torch.sqrt(st[:, 0, R.S_D2]) / (eps + torch.sqrt(st[:, 0, R.S_G2]))).to(x.dtype)
+        d = torch.norm(x.reshape(n, -1) - y.reshape(n, -1), self.p, 1)
+        return d / (eps + torch.norm(y.reshape(n, -1), self.p, 1))
+
+    def __call__(self, x, y, eps=1e-20):
+        return self._reduce(self._ratio(x, y, eps))
+
+
+class FftLpLoss(LpLoss):
+    """eval/metrics.py:626-678 — the same ratio on the Fourier coefficients (rocFFT through torch.fft), optionally on
+    the band flow <= k < fhigh of every transformed axis; |z|^2 sums for p = 2 come from the statistics kernel on the
+    real view of the complex coefficients."""
+
+    def __call__(self, x, y, flow=None, fhigh=None, eps=1e-20):
+        dims = list(range(1, len(x.shape)))
+        xf = torch.fft.fftn(x, dim=dims)
+        yf = torch.fft.fftn(y, dim=dims)
+        lo = 0 if flow is None else flow
+        hi = int(np.max(xf.shape[1:])) if fhigh is None else fhigh
+        if 1 <= len(dims) <= 4:
+            sl = (slice(None),) + (slice(lo, hi),) * len(dims)
+            xf, yf = xf[sl], yf[sl]
+        yf = yf.reshape(xf.shape)
+        if self.p == 2:
+            r = self._ratio(torch.view_as_real(xf.contiguous()), torch.view_as_real(yf.contiguous()), eps)
+        else:
+            n = x.size()[0]
+            r = torch.norm((xf - yf).reshape(n, -1), self.p, 1) / (eps + torch.norm(yf.reshape(n, -1), self.p, 1))
+        return self._reduce(r)
 
 
 def compute_rse(pred, target, eps: float = 1e-8) -> torch.Tensor:

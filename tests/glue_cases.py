@@ -84,6 +84,22 @@ def check_metrics(dev):
     assert isinstance(mr, float) and abs(mr - float(d["mean_rse"])) <= 1e-4 * float(d["mean_rse"])
 
 
+def check_pdebench_and_lp(dev):
+    d = gold()
+    p, g = _t(d["pred"], dev), _t(d["target"], dev)
+    avg, per = PM.compute_pdebench_nrmse(p[:, 0], g[:, 0])
+    assert isinstance(avg, float) and isinstance(per, list) and len(per) == 18
+    assert _rel(np.asarray(per), d["pdebench_nrmse"]) <= RTOL and abs(avg - float(d["pdebench_nrmse_avg"])) <= RTOL * avg
+    x, y = p[:, 0, ..., 2].contiguous(), g[:, 0, ..., 2].contiguous()
+    for pn in (1, 2, 3):
+        for red in ("none", "mean", "sum"):
+            got = PM.LpLoss(p=pn, reduction=red)(x, y)
+            assert _rel(got.cpu().numpy(), d[f"lp{pn}_{red}"]) <= RTOL, (pn, red)
+    assert _rel(PM.FftLpLoss(p=2, reduction="none")(x, y).cpu().numpy(), d["fftlp2_none"]) <= RTOL
+    assert _rel(PM.FftLpLoss(p=2, reduction="mean")(x, y, flow=1, fhigh=5).cpu().numpy(), d["fftlp2_band_mean"]) <= 5 * RTOL
+    assert _rel(PM.FftLpLoss(p=1, reduction="sum")(x, y).cpu().numpy(), d["fftlp1_sum"]) <= 5 * RTOL
+
+
 def check_accumulator(dev):
     gen = torch.Generator().manual_seed(3)
     batches = [(torch.randn(2, 3, 6, 5, 18, generator=gen), torch.randn(2, 3, 6, 5, 18, generator=gen)) for _ in range(3)]

@@ -57,6 +57,24 @@ def test_oracle_metrics_match_golden():
     assert np.allclose(GO.rse(p[..., :3], g[..., :3]).numpy(), d["rse"], rtol=1e-12)
 
 
+def test_oracle_pdebench_and_lp_match_golden():
+    d = GC.gold()
+    p, g = torch.tensor(d["pred"]), torch.tensor(d["target"])
+    avg, per = GO.pdebench_nrmse(p[:, 0], g[:, 0])
+    assert np.allclose(per, d["pdebench_nrmse"], rtol=1e-12) and abs(avg - float(d["pdebench_nrmse_avg"])) < 1e-12
+    x, y = p[:, 0, ..., 2], g[:, 0, ..., 2]
+    for pn in (1, 2, 3):
+        for red in ("none", "mean", "sum"):
+            assert np.allclose(GO.lp_loss(x, y, pn, red).numpy(), d[f"lp{pn}_{red}"], rtol=1e-12)
+    assert np.allclose(GO.fft_lp_loss(x, y, 2, "none").numpy(), d["fftlp2_none"], rtol=1e-12)
+    assert np.allclose(GO.fft_lp_loss(x, y, 2, "mean", 1, 5).numpy(), d["fftlp2_band_mean"], rtol=1e-12)
+    assert np.allclose(GO.fft_lp_loss(x, y, 1, "sum").numpy(), d["fftlp1_sum"], rtol=1e-12)
+
+
+def test_pdebench_and_lp_host_logic():
+    GC.check_pdebench_and_lp(CPU)
+
+
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_oracle_metric_func_matches_golden(tag):
     d = np.load(GC.os.path.join(GC.GOLD, "metric_func.npz"))

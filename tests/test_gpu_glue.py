@@ -177,3 +177,7 @@ def test_full_size_metric_properties():
         assert torch.equal(out.grad[..., ci], y[:, 1:])
     others = [c for c in range(C) if c not in (0, 1, 15)]
     assert float(out.grad[..., others].abs().max()) == 0.0
+
+
+def test_pdebench_and_lp():
+    GC.check_pdebench_and_lp(DEV)

@@ -265,6 +265,19 @@ def run_glue():
     out["rse"] = f(pred[..., :3], tgt[..., :3]).numpy()
     f = load_function("eval/eval_autoregressive.py", "compute_mean_rse", dict(compute_rse=f))
     out["mean_rse"] = np.asarray(float(f(pred[..., :3], tgt[..., :3])))
+    # PDEBench-style metrics: per-channel nRMSE with the global std (eval/eval_omni.py) and the Lp / Fourier-Lp losses
+    f = load_function("eval/eval_omni.py", "compute_pdebench_nrmse")
+    avg, per = f(pred[:, 0], tgt[:, 0])
+    out["pdebench_nrmse_avg"], out["pdebench_nrmse"] = np.asarray(float(avg)), np.asarray([float(v) for v in per])
+    from eval.metrics import LpLoss, FftLpLoss
+    x, y = pred[:, 0, ..., 2], tgt[:, 0, ..., 2]              # [B, H, W]
+    for pn in (1, 2, 3):
+        out[f"lp{pn}_none"] = LpLoss(p=pn, reduction="none")(x, y).numpy()
+        out[f"lp{pn}_mean"] = LpLoss(p=pn, reduction="mean")(x, y).numpy()
+        out[f"lp{pn}_sum"] = LpLoss(p=pn, reduction="sum")(x, y).numpy()
+    out["fftlp2_none"] = FftLpLoss(p=2, reduction="none")(x, y).numpy()
+    out["fftlp2_band_mean"] = FftLpLoss(p=2, reduction="mean")(x, y, flow=1, fhigh=5).numpy()
+    out["fftlp1_sum"] = FftLpLoss(p=1, reduction="sum")(x, y).numpy()
     return out
 
 
