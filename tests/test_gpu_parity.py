@@ -308,7 +308,7 @@ def _full_size_properties(mod, fields, extra, shifts, modes=("auto",)):
 
 
 def test_full_size_taylor_green_properties():
-    """BASELINE configuration C2: B=16, T=16, 256 x 256, three fields"""
+    """the benchmark configuration: B=16, T=16, 256 x 256, three fields"""
     dev = _dev()
     gen = torch.Generator(device=dev).manual_seed(31)
     fields = [torch.randn(16, 16, 256, 256, generator=gen, device=dev) * 0.5 for _ in range(3)]
@@ -330,7 +330,7 @@ def test_full_size_taylor_green_properties():
 
 
 def test_full_size_burgers3d_properties():
-    """BASELINE configuration C5: one sample of 128^3, three fields (stored-residual kernels)"""
+    """the 3-D benchmark configuration: one sample of 128^3, three fields (stored-residual kernels)"""
     dev = _dev()
     gen = torch.Generator(device=dev).manual_seed(32)
     fields = [torch.randn(1, 9, 128, 128, 128, generator=gen, device=dev) * 0.5 for _ in range(3)]
