@@ -172,6 +172,14 @@ int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer
                            const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scales,
                            float* grad, void* stream);
 
+/* compute_vrmse's epilogue (finetune/train_taylor_green_2d_lora_v3.py:215-232) on the statistics of ONE group as
+ * pde_amd_pair_stats leaves them, stats[channels][PDE_AMD_NSTAT]: over the n_valid <= 64 listed channels (host array)
+ *   out[0] = mean_c sqrt( (sum d^2 / rows) / (sum g^2 / rows - (sum g / rows)^2 + 1e-8) )        (vrmse)
+ *   out[1] = sqrt( sum_c sum d^2 / (rows * n_valid) + 1e-8 )                                       (rmse)
+ * as fp32 device scalars; NaN for an empty list, like the mean of an empty tensor. */
+int pde_amd_vrmse_from_stats(const double* stats, int32_t channels, const int32_t* valid, int32_t n_valid, int64_t rows,
+                             float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * compute_pde_loss glue (finetune/train_taylor_green_2d_lora_v3.py:169-201, train_rayleigh_benard_lora_v3.py:178-216,
  * train_burgers_1d_lora_v3.py:142-172, train_heat_3d_lora_v3.py:144-172, train_fullft_physonly.py:172-223):

@@ -323,6 +323,32 @@ inline bool tile_path_ok(long S, int C, const void* p0, const void* p1) {
          ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1)) & 15) == 0;
 }
 
+// (vrmse, rmse) of the listed channels from one group's statistics: a single wave, one channel per lane
+struct VrmseArgs {
+  const double* stats;      // [C][NSTAT]
+  int32_t ch[64];
+  int n;
+  double rows;
+};
+__global__ __launch_bounds__(64) void vrmse_kernel(const VrmseArgs a, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  double v = 0.0, d2 = 0.0;
+  if (i < a.n) {
+    const double* st = a.stats + (long)a.ch[i] * NSTAT;
+    d2 = st[0];
+    const double mean_g = st[2] / a.rows;
+    const double var = st[1] / a.rows - mean_g * mean_g;
+    v = sqrt((d2 / a.rows) / (var + 1e-8));
+  }
+  v = wave_sum_d(v);
+  d2 = wave_sum_d(d2);
+  if (i == 0) {
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    out[0] = a.n ? (float)(v / a.n) : (float)nan;                                   // mean over an empty channel list
+    out[1] = a.n ? (float)sqrt(d2 / (a.rows * a.n) + 1e-8) : (float)nan;
+  }
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP; }
 
 }  // namespace
@@ -356,6 +382,19 @@ int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, i
                      (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, partial);
   hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)((NSTAT * channels + 3) / 4), (unsigned)groups), dim3(256), 0, st, partial,
                      pl.blocks_per_group, (int)channels, stats);
+  return check_launch();
+}
+
+int pde_amd_vrmse_from_stats(const double* stats, int32_t channels, const int32_t* valid, int32_t n_valid, int64_t rows,
+                             float* out, void* stream) {
+  if (!stats || !out || channels <= 0 || n_valid < 0 || n_valid > 64 || rows <= 0 || (n_valid && !valid)) return PDE_AMD_EINVAL;
+  VrmseArgs a;
+  a.stats = stats; a.n = n_valid; a.rows = (double)rows;
+  for (int i = 0; i < n_valid; ++i) {
+    if (valid[i] < 0 || valid[i] >= channels) return PDE_AMD_EINVAL;
+    a.ch[i] = valid[i];
+  }
+  hipLaunchKernelGGL(vrmse_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
   return check_launch();
 }
 

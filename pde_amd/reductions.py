@@ -49,6 +49,14 @@ class HipReductions:
                                         stats.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "pair_stats")
         return stats
 
+    def vrmse_from_stats(self, stats, valid: Sequence[int], rows: int):
+        """[2] fp32 (vrmse, rmse) from one group's statistics [C, NSTAT]; at most 64 valid channels."""
+        out = torch.empty(2, dtype=torch.float32, device=stats.device)
+        arr = (C.c_int32 * max(len(valid), 1))(*[int(v) for v in valid])
+        _lib.check(_lib.lib().pde_amd_vrmse_from_stats(stats.data_ptr(), int(stats.shape[0]), arr, len(valid), int(rows),
+                                                       out.data_ptr(), _stream(stats)), "vrmse_from_stats")
+        return out
+
     @staticmethod
     def _term_array(terms: Sequence["_lib.Term"]):
         arr = (_lib.Term * len(terms))()

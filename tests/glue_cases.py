@@ -74,6 +74,8 @@ def check_metrics(dev):
     v, r = PM.compute_vrmse(p, g, m)
     assert abs(float(v) - float(d["vrmse"])) <= RTOL * float(d["vrmse"])
     assert abs(float(r) - float(d["rmse"])) <= RTOL * float(d["rmse"])
+    v0, r0 = PM.compute_vrmse(p, g, torch.zeros_like(m))          # no valid channel: means over nothing
+    assert torch.isnan(v0) and torch.isnan(r0)
     s = PM.nrmse_per_sample(p[:, 0, ..., 3], g[:, 0, ..., 3])
     assert _rel(s.cpu().numpy(), d["nrmse_per_sample"]) <= RTOL
     pc = PM.nrmse_per_channel(p[:, 0], g[:, 0], [(0, "vx"), (1, "vy"), (15, "p")])

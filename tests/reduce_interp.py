@@ -17,6 +17,17 @@ def _np(t):
 class InterpReductions:
     name = "interp"
 
+    def vrmse_from_stats(self, stats, valid, rows):
+        st = _np(stats)
+        if not len(valid):
+            return torch.full((2,), float("nan"))
+        sel = st[list(valid)]
+        n = float(rows)
+        var = sel[:, R.S_G2] / n - (sel[:, R.S_G] / n) ** 2
+        v = np.sqrt((sel[:, R.S_D2] / n) / (var + 1e-8)).mean()
+        r = np.sqrt(sel[:, R.S_D2].sum() / (n * len(valid)) + 1e-8)
+        return torch.tensor([v, r], dtype=torch.float32)
+
     def pair_stats(self, pred, target, groups, rows, channels, rse_eps=1e-8):
         p = _np(pred).reshape(groups, rows, channels)
         g = _np(target).reshape(groups, rows, channels)
