@@ -170,13 +170,14 @@ __global__ __launch_bounds__(256) void term_fwd_kernel(const TermArgs a, double*
 
 struct BlockTable { int start[PDE_AMD_MAX_TERMS + 1]; };
 
-__global__ void term_finalize_kernel(const double* __restrict__ partial, const BlockTable blk, int n_terms, double* __restrict__ sums) {
-  const int t = threadIdx.x;
-  if (t < n_terms) {
-    double r = 0.0;
-    for (int b = blk.start[t]; b < blk.start[t + 1]; ++b) r += partial[b];
-    sums[t] = r;
-  }
+// one wave per term: lanes stride over the term's block partials, then a shuffle tree (fixed order)
+__global__ __launch_bounds__(64) void term_finalize_kernel(const double* __restrict__ partial, const BlockTable blk, int n_terms, double* __restrict__ sums) {
+  const int t = blockIdx.x;
+  if (t >= n_terms) return;
+  double r = 0.0;
+  for (int b = blk.start[t] + (int)threadIdx.x; b < blk.start[t + 1]; b += 64) r += partial[b];
+  r = wave_sum_d(r);
+  if (threadIdx.x == 0) sums[t] = r;
 }
 
 // grad[...] += scale * 2 * value * coef_j at every tap; offsets inside one term never collide
@@ -436,7 +437,7 @@ int pde_amd_terms_forward(const float* pred, const float* target, int64_t outer,
     blk_start[k + 1] = blk_start[k] + nb;
     if (nb) hipLaunchKernelGGL(term_fwd_kernel, dim3(nb), dim3(256), 0, st, a, partial + blk_start[k]);
   }
-  hipLaunchKernelGGL(term_finalize_kernel, dim3(1), dim3(64), 0, st, partial, blk, (int)n_terms, sums);
+  hipLaunchKernelGGL(term_finalize_kernel, dim3((unsigned)n_terms), dim3(64), 0, st, partial, blk, (int)n_terms, sums);
   return check_launch();
 }
 
