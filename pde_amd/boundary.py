@@ -8,6 +8,7 @@ torch on [n_terms] numbers, so autograd chains it.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -19,10 +20,23 @@ from .sink import sink_of
 CH_VX, CH_VY = 0, 1      # finetune/train_ns_incom_lora_v3.py:74-75
 
 
+_last_mask = [None, -1, None]      # weak reference to the mask tensor last read, its version counter, the channel list
+
+
 def valid_channels(channel_mask: torch.Tensor) -> List[int]:
-    """`torch.where(mask > 0)[0]` of the first row (finetune/train_taylor_green_2d_lora_v3.py:141-144)."""
+    """`torch.where(mask > 0)[0]` of the first row (finetune/train_taylor_green_2d_lora_v3.py:141-144).  Reading the list
+    synchronises with the device, as in the reference; the losses and metrics of one batch share the same mask tensor, so
+    the answer for that very tensor (same object, not modified in place since) is remembered and the batch pays once."""
+    ref, version, ch = _last_mask
+    if ref is not None and ref() is channel_mask and version == channel_mask._version:
+        return list(ch)
     m = channel_mask if channel_mask.dim() == 1 else channel_mask[0]
-    return [int(i) for i in torch.where(m > 0)[0].tolist()]
+    ch = [int(i) for i in torch.where(m > 0)[0].tolist()]
+    try:
+        _last_mask[:] = [weakref.ref(channel_mask), channel_mask._version, ch]
+    except TypeError:
+        _last_mask[:] = [None, -1, None]
+    return list(ch)
 
 
 class TermSet:
