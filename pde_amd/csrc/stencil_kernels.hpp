@@ -391,35 +391,72 @@ __global__ __launch_bounds__(64) void totals_kernel(const double* __restrict__ s
   if (threadIdx.x == 0) totals[NE] = tot;
 }
 
-// Both of the above in one launch for small problems: one workgroup of 16 waves; wave w sums the partials of
-// samples w, w+16, ... (lanes stride over a sample's items), then thread 0 adds the per-wave totals in wave order.
-// Fixed order, so repeatable; it saves a launch and the gap between two tiny kernels.
+// Both of the above in one launch for small problems: one workgroup of 16 waves.  With 16 or more samples wave w sums
+// the partials of samples w, w+16, ... (lanes stride over a sample's items); with fewer, 16/B waves share a sample's
+// items in contiguous segments that one thread then adds in segment order.  Thread 0 adds the per-slot totals in slot
+// order.  Fixed order, so repeatable; it saves a launch and the gap between two tiny kernels.
 template <int NE>
 __global__ __launch_bounds__(1024) void finalize_totals_kernel(const double* __restrict__ partial, double* __restrict__ sums,
                                                                float* __restrict__ totals, int items, int B) {
   __shared__ double s_tot[16 * NE];
+  __shared__ double s_seg[16 * NE];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double tot[NE];
+  const int nseg = B >= 16 ? 1 : 16 / B;      // waves per sample
+  if (nseg == 1) {
+    double tot[NE];
 #pragma unroll
-  for (int k = 0; k < NE; ++k) tot[k] = 0.0;
-  for (int b = wv; b < B; b += 16) {
+    for (int k = 0; k < NE; ++k) tot[k] = 0.0;
+    for (int b = wv; b < B; b += 16) {
+      double acc[NE];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) acc[k] = 0.0;
+      const double* p = partial + (long)b * items * NE;
+      for (int i = lane; i < items; i += 64) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) acc[k] += p[(long)i * NE + k];
+      }
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const double s = wave_sum(acc[k]);      // complete in lane 0
+        if (lane == 0) { sums[(long)b * NE + k] = s; tot[k] += s; }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NE; ++k) s_tot[wv * NE + k] = tot[k];
+    }
+  } else {
+    const int b = wv / nseg, sg = wv % nseg;
     double acc[NE];
 #pragma unroll
     for (int k = 0; k < NE; ++k) acc[k] = 0.0;
-    const double* p = partial + (long)b * items * NE;
-    for (int i = lane; i < items; i += 64) {
+    if (b < B) {
+      const int len = (items + nseg - 1) / nseg;
+      const int lo = sg * len, hi = lo + len < items ? lo + len : items;
+      const double* p = partial + (long)b * items * NE;
+      for (int i = lo + lane; i < hi; i += 64) {
 #pragma unroll
-      for (int k = 0; k < NE; ++k) acc[k] += p[(long)i * NE + k];
+        for (int k = 0; k < NE; ++k) acc[k] += p[(long)i * NE + k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
-      const double s = wave_sum(acc[k]);      // complete in lane 0
-      if (lane == 0) { sums[(long)b * NE + k] = s; tot[k] += s; }
+      const double s = wave_sum(acc[k]);
+      if (lane == 0) s_seg[wv * NE + k] = s;
     }
-  }
-  if (lane == 0) {
+    __syncthreads();
+    if (threadIdx.x < 16) {      // thread b: its sample's segments in order; slots past the last sample hold zero
+      const int bb = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < NE; ++k) s_tot[wv * NE + k] = tot[k];
+      for (int k = 0; k < NE; ++k) {
+        double s = 0.0;
+        if (bb < B) {
+          for (int g = 0; g < nseg; ++g) s += s_seg[(bb * nseg + g) * NE + k];
+          sums[(long)bb * NE + k] = s;
+        }
+        s_tot[bb * NE + k] = s;
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -769,7 +806,10 @@ struct MarchOK {
                                 P::GTLO <= 1 && P::GTHI <= 1;
 };
 
-constexpr int LDS_BUDGET = 96 * 1024;   // keep at least one other workgroup's worth of LDS free per CU
+#ifndef PDE_AMD_LDS_BUDGET
+#define PDE_AMD_LDS_BUDGET (96 * 1024)
+#endif
+constexpr int LDS_BUDGET = PDE_AMD_LDS_BUDGET;   // keep at least one other workgroup's worth of LDS free per CU
 
 template <class P>
 struct BwdMarchFits {

@@ -797,6 +797,24 @@ __device__ __forceinline__ void stage_tile(float* tile, const float* __restrict_
   st.store(v, tile);
 }
 
+// Staging of N tiles of one shape with every load in flight before the first LDS write: the workgroup is exposed to
+// the memory latency once, not once per tile, and the offsets are computed once.
+template <class TL, bool P0, bool P1, bool P2, int NT, int W, int N>
+struct MultiStage {
+  using St = StagerQ<TL, P0, P1, P2, NT, W>;
+  using fv = typename VecOf<W>::type;
+  St st;
+  fv v[N][St::EPT];
+  __device__ __forceinline__ void init(int o0, int o1, int o2, const Geom& g) { st.init(o0, o1, o2, g); }
+  __device__ __forceinline__ void fetch(int n, const float* __restrict__ src) { st.fetch(v[n], src); }
+  // tile = scale * fetched values; `on` false (wave-uniform) stores zeros whatever was fetched
+  __device__ __forceinline__ void store(int n, float* __restrict__ tile, float scale, bool on = true) {
+#pragma unroll
+    for (int j = 0; j < St::EPT; ++j) v[n][j] = on ? v[n][j] * scale : vec_zero<W>();
+    st.store(v[n], tile);
+  }
+};
+
 template <class TL, int NT, int W>
 __device__ __forceinline__ void zero_tile_q(float* tile) {
   using fv = typename VecOf<W>::type;
@@ -881,8 +899,31 @@ __global__ __launch_bounds__((FrameCfg<P, W>::NT)) void fwd_frame_q_kernel(const
   const int o2 = (tile % g.nt2) * TL::T2, o1 = ((tile / g.nt2) % g.nt1) * TL::T1, o0 = (tile / (g.nt2 * g.nt1)) * TL::T0;
   const long frame = ((long)b * g.T + t) * g.S;
 
+  // every global load of the workgroup is issued before the first wait: the frame's halo tiles and (when the other
+  // frames need no halo) this lane's own quads of those frames
+  MultiStage<TL, P::PER0, P::PER1, P::PER2, NT, W, P::NF> ms;
+  ms.init(o0, o1, o2, g);
 #pragma unroll
-  for (int f = 0; f < P::NF; ++f) stage_tile<TL, P::PER0, P::PER1, P::PER2, NT, W>(s_f + f * TL::SIZE, a.f[f] + frame, o0, o1, o2, g, 1.0f);
+  for (int f = 0; f < P::NF; ++f) ms.fetch(f, a.f[f] + frame);
+  fv fcq[QPT][NTS > 0 ? NTS : 1][P::NF];
+  if (!TT_ON) {
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      const int row = (threadIdx.x / QR) * QPT + q;
+      const int l2 = W * owned_quad<QR, TL::S1, W>(), l1 = row % TL::T1, l0 = row / TL::T1;
+      const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+      const bool inside = i0 < g.N0 && i1 < g.N1 && i2 < g.N2;
+      const long goff = inside ? ((long)i0 * g.N1 + i1) * g.N2 + i2 : 0;
+#pragma unroll
+      for (int s = 0; s < NTS; ++s) {
+        const int ot = s < P::TLO ? s - P::TLO : s - P::TLO + 1;
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) fcq[q][s][f] = *reinterpret_cast<const fv*>(a.f[f] + frame + (long)ot * g.S + goff);
+      }
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < P::NF; ++f) ms.store(f, s_f + f * TL::SIZE, 1.0f);
   if (TT_ON) {
 #pragma unroll
     for (int s = 0; s < NTS; ++s) {
@@ -923,9 +964,8 @@ __global__ __launch_bounds__((FrameCfg<P, W>::NT)) void fwd_frame_q_kernel(const
     if (!TT_ON) {
 #pragma unroll
       for (int s = 0; s < NTS; ++s) {
-        const int ot = s < P::TLO ? s - P::TLO : s - P::TLO + 1;
 #pragma unroll
-        for (int f = 0; f < P::NF; ++f) acc.fc[s][f] = *reinterpret_cast<const fv*>(a.f[f] + frame + (long)ot * g.S + goff);
+        for (int f = 0; f < P::NF; ++f) acc.fc[s][f] = fcq[q][s][f];
       }
     }
     float Rq[W][P::NE];
@@ -1062,11 +1102,45 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
     for (int k = 0; k < P::NE; ++k) cf[s][k] = ok ? up[k] * ldc(a.wt, k * g.TR + max(min(trs, g.TR - 1), 0)) : 0.0f;
   }
 
+  // Every global load of the workgroup is issued before the first wait.  A residual frame outside the range has a
+  // zero coefficient: its load is aimed at the nearest frame inside and the value is dropped.
+  const int trc = max(min(tr0, g.TR - 1), 0);
+  MultiStage<TG, P::PER0, P::PER1, P::PER2, NT, W, P::NE> msg;
+  msg.init(o0, o1, o2, g);
+#pragma unroll
+  for (int k = 0; k < P::NE; ++k) msg.fetch(k, rp[k] + (long)trc * g.S);
+  MultiStage<TA, P::PER0, P::PER1, P::PER2, NT, W, AF_ON ? P::NF : 1> msa;
+  if (AF_ON) {
+    msa.init(o0, o1, o2, g);
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) msa.fetch(f, a.f[f] + frame);
+  }
+  fv gcq[QPT][NG][P::NE];
+  if (!GT_ON) {
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      const int row = (threadIdx.x / QR) * QPT + q;
+      const int l2 = W * owned_quad<QR, TG::S1, W>(), l1 = row % TG::T1, l0 = row / TG::T1;
+      const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+      const bool inside = i0 < g.N0 && i1 < g.N1 && i2 < g.N2;
+      const long goff = inside ? ((long)i0 * g.N1 + i1) * g.N2 + i2 : 0;
+#pragma unroll
+      for (int s = 0; s < NG; ++s) {
+        if (s == P::GTLO) continue;
+        const int trs = max(min(tr0 + s - P::GTLO, g.TR - 1), 0);
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) gcq[q][s][k] = *reinterpret_cast<const fv*>(rp[k] + (long)trs * g.S + goff);
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) {
     const float cfk = cf[P::GTLO][k];      // wave-uniform
-    if (cfk != 0.0f) stage_tile<TG, P::PER0, P::PER1, P::PER2, NT, W>(s_g + k * TG::SIZE, rp[k] + (long)tr0 * g.S, o0, o1, o2, g, cfk);
-    else zero_tile_q<TG, NT, W>(s_g + k * TG::SIZE);
+    msg.store(k, s_g + k * TG::SIZE, cfk, cfk != 0.0f);
+  }
+  if (AF_ON) {
+#pragma unroll
+    for (int f = 0; f < P::NF; ++f) msa.store(f, s_a + f * TA::SIZE, 1.0f);
   }
   if (GT_ON) {
 #pragma unroll
@@ -1080,10 +1154,6 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
         else zero_tile_q<TGT, NT, W>(dst);
       }
     }
-  }
-  if (AF_ON) {
-#pragma unroll
-    for (int f = 0; f < P::NF; ++f) stage_tile<TA, P::PER0, P::PER1, P::PER2, NT, W>(s_a + f * TA::SIZE, a.f[f] + frame, o0, o1, o2, g, 1.0f);
   }
   if (AUX_ON) {
 #pragma unroll
@@ -1110,9 +1180,7 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
 #pragma unroll
           for (int k = 0; k < P::NE; ++k) {
             const float cfk = cf[s][k];
-            fv v = vec_zero<W>();
-            if (cfk != 0.0f) v = *reinterpret_cast<const fv*>(rp[k] + (long)(tr0 + s - P::GTLO) * g.S + goff) * cfk;
-            acc.gc[s][k] = v;
+            acc.gc[s][k] = cfk != 0.0f ? gcq[q][s][k] * cfk : vec_zero<W>();
           }
         }
       }

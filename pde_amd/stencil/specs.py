@@ -434,7 +434,9 @@ def _ape_burgers3d():
     for phi in (u, v, w):
         conv = 0.5 * (g(phi * u, 0) + g(phi * v, 1) + g(phi * w, 2))
         res.append(_ddt(b, phi) + b1 * conv - a2 * lap(phi))
-    return b.done(res, **T3D)
+    # per-frame kernels (the time ring of 3-D halo tiles does not fit LDS): a near-cubic tile reads 3.4 halo floats per
+    # point instead of 5.1 and leaves room for three workgroups per CU
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16)})
 
 
 def _swift_hohenberg3d():
