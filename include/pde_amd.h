@@ -180,6 +180,14 @@ int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer
 int pde_amd_vrmse_from_stats(const double* stats, int32_t channels, const int32_t* valid, int32_t n_valid, int64_t rows,
                              float* out, void* stream);
 
+/* The radial binning of metric_func's Fourier-band error (eval/metrics.py:258-296: the Python loops over wave numbers
+ * that add |F|^2 into bin floor(|k|)).  spectrum: complex64 [groups][points][nt] (re, im interleaved), device;
+ * the bins as a CSR list on the device: members of bin i are point_index[bin_start[i] .. bin_start[i+1]), each a
+ * point number < points.  out[groups][nbins][nt] (fp32, device) = sum over the bin's members of |spectrum|^2, added
+ * in list order with fp64 accumulation (repeatable; no atomics). */
+int pde_amd_band_power(const float* spectrum, int64_t groups, int64_t points, int32_t nt, const int32_t* bin_start,
+                       const int32_t* point_index, int32_t nbins, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * compute_pde_loss glue (finetune/train_taylor_green_2d_lora_v3.py:169-201, train_rayleigh_benard_lora_v3.py:178-216,
  * train_burgers_1d_lora_v3.py:142-172, train_heat_3d_lora_v3.py:144-172, train_fullft_physonly.py:172-223):

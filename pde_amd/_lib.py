@@ -63,6 +63,7 @@ SIGNATURES = {
     "pde_amd_pair_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "pde_amd_vrmse_from_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pde_amd_band_power": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "pde_amd_terms_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "pde_amd_terms_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(Term), C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

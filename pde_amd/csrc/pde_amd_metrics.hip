@@ -352,6 +352,41 @@ __global__ __launch_bounds__(64) void vrmse_kernel(const VrmseArgs a, float* __r
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP; }
 
+
+// ------------------------------------------------------------------------------------------------
+// Radial Fourier-band sums: out[g][bin][t] = sum over the wavenumbers of the bin of |F[g][point][t]|^2.
+// F is complex64 [groups][points][nt] (re, im interleaved); the bins arrive as a CSR list (bin_start, point index),
+// so every (group, bin) pair is one workgroup that adds its members in a fixed order: repeatable, no atomics.
+// Lanes are laid out as (member, frame) with TT frames side by side, TT a power of two <= 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void band_power_kernel(const float2* __restrict__ F, const int* __restrict__ bin_start,
+                                                         const int* __restrict__ point, long points, int nt, int TT,
+                                                         int nbins, float* __restrict__ out) {
+  __shared__ double s_acc[256];
+  const int bin = blockIdx.x;
+  const long g = blockIdx.y;
+  const int lo = bin_start[bin], hi = bin_start[bin + 1];
+  const int tl = threadIdx.x % TT, ml = threadIdx.x / TT, MS = 256 / TT;
+  const float2* Fg = F + g * points * nt;
+  for (int t0 = 0; t0 < nt; t0 += TT) {
+    const int t = t0 + tl;
+    double acc = 0.0;
+    if (t < nt) {
+      for (int m = lo + ml; m < hi; m += MS) {
+        const float2 v = Fg[(long)point[m] * nt + t];
+        acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+      }
+    }
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < TT && t < nt) {
+      double s = 0.0;
+      for (int j = 0; j < MS; ++j) s += s_acc[j * TT + threadIdx.x];
+      out[(g * nbins + bin) * nt + t] = (float)s;
+    }
+    __syncthreads();
+  }
+}
 }  // namespace
 }  // namespace pde_amd
 
@@ -396,6 +431,19 @@ int pde_amd_vrmse_from_stats(const double* stats, int32_t channels, const int32_
     a.ch[i] = valid[i];
   }
   hipLaunchKernelGGL(vrmse_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+  return check_launch();
+}
+
+int pde_amd_band_power(const float* spectrum, int64_t groups, int64_t points, int32_t nt, const int32_t* bin_start,
+                       const int32_t* point_index, int32_t nbins, float* out, void* stream) {
+  if (groups < 0 || points < 0 || nt < 0 || nbins < 0) return PDE_AMD_EINVAL;
+  if (groups == 0 || nbins == 0 || nt == 0) return PDE_AMD_OK;
+  if (!spectrum || !bin_start || !point_index || !out) return PDE_AMD_EINVAL;
+  if (groups > 65535 || points * (int64_t)nt >= (1LL << 31)) return PDE_AMD_ESHAPE;
+  int TT = 1;
+  while (TT < nt && TT < 64) TT *= 2;
+  hipLaunchKernelGGL(band_power_kernel, dim3((unsigned)nbins, (unsigned)groups), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(spectrum), bin_start, point_index, (long)points, (int)nt, TT, (int)nbins, out);
   return check_launch();
 }
 

@@ -199,21 +199,32 @@ class NRMSEAccumulator:
         return out
 
 
-_BIN_CACHE: Dict[tuple, torch.Tensor] = {}
+_BIN_CACHE: Dict[tuple, tuple] = {}
 
 
-def _radial_bins(shape: Sequence[int], device) -> Tuple[torch.Tensor, int]:
-    """Bin index floor(|k|) of every wavenumber of the low half-spectrum box, -1 where the reference skips it
-    (eval/metrics.py:271-276, :284-290)."""
+def _radial_bins(shape: Sequence[int], device) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """The radial bins of the low half-spectrum box as a CSR list: (bin_start[nbins + 1], point_index, nbins), where a
+    point is the flat index of a wavenumber in the full spectrum grid and its bin is floor(|k|); wavenumbers whose bin
+    lies past the last one are left out, as the reference skips them (eval/metrics.py:271-276, :284-290)."""
     key = (tuple(shape), str(device))
-    nb = min(n // 2 for n in shape)
+    nbins = min(n // 2 for n in shape)
     if key not in _BIN_CACHE:
-        grids = torch.meshgrid(*[torch.arange(n // 2, dtype=torch.float64) for n in shape], indexing="ij")
-        r2 = sum(g * g for g in grids)
-        it = torch.floor(torch.sqrt(r2)).to(torch.int64)
-        it = torch.where(it > nb - 1, torch.full_like(it, -1), it)
-        _BIN_CACHE[key] = it.to(device)
-    return _BIN_CACHE[key], nb
+        axes = [np.arange(n // 2) for n in shape]
+        grids = np.meshgrid(*axes, indexing="ij")
+        r2 = sum(g.astype(np.float64) ** 2 for g in grids)
+        it = np.floor(np.sqrt(r2)).astype(np.int64).reshape(-1)
+        flat = np.zeros_like(grids[0])
+        for g, n in zip(grids, shape):
+            flat = flat * n + g
+        flat = flat.reshape(-1)
+        keep = it <= nbins - 1
+        it, flat = it[keep], flat[keep]
+        order = np.argsort(it, kind="stable")      # members of a bin in grid order
+        start = np.zeros(nbins + 1, dtype=np.int64)
+        np.cumsum(np.bincount(it, minlength=nbins), out=start[1:])
+        _BIN_CACHE[key] = (torch.from_numpy(start.astype(np.int32)).to(device),
+                           torch.from_numpy(flat[order].astype(np.int32)).to(device))
+    return (*_BIN_CACHE[key], nbins)
 
 
 def metric_func(pred, target, if_mean: bool = True, Lx: float = 1.0, Ly: float = 1.0, Lz: float = 1.0,
@@ -223,7 +234,7 @@ def metric_func(pred, target, if_mean: bool = True, Lx: float = 1.0, Ly: float =
 
     RMSE, nRMSE, MPP-nRMSE, the conserved-sum error and the max error come from one pair_stats pass with
     (frame, channel) as the channel axis; the boundary RMSE runs the same kernel on the boundary slabs.  The
-    Fourier-band term uses rocFFT through torch.fft and one index_add for the radial bins."""
+    Fourier-band term uses rocFFT through torch.fft and the band_power kernel for the radial bins."""
     if pred.dim() not in (4, 5, 6):
         raise ValueError("metric_func expects [nb, nx(, ny(, nz)), nt, nc]")
     be = R.get_backend()
@@ -275,13 +286,8 @@ def metric_func(pred, target, if_mean: bool = True, Lx: float = 1.0, Ly: float =
         _err_F = torch.sqrt((dF.abs() ** 2).mean(0)) / sp[0] * Lx       # [nc, nx/2+1, nt]
     else:
         dF = torch.fft.fftn(d, dim=list(range(2, 2 + nd)))
-        e2 = dF.abs() ** 2
-        low = e2[(slice(None), slice(None)) + tuple(slice(0, n // 2) for n in sp)]
-        bins, nbins = _radial_bins(sp, pred.device)
-        flat = low.reshape(nb, nc, -1, nt)
-        keep = bins.reshape(-1) >= 0
-        acc = torch.zeros(nb, nc, nbins, nt, dtype=flat.dtype, device=pred.device)
-        acc.index_add_(2, bins.reshape(-1)[keep], flat[:, :, keep])
+        start, members, nbins = _radial_bins(sp, pred.device)
+        acc = be.band_power(dF.reshape(nb * nc, S, nt), start, members, nbins).view(nb, nc, nbins, nt)
         vol = float(S)
         L = Lx * Ly if nd == 2 else Lx * Ly * Lz
         _err_F = torch.sqrt(acc.mean(0)) / vol * L                       # [nc, nbins, nt]

@@ -57,6 +57,17 @@ class HipReductions:
                                                        out.data_ptr(), _stream(stats)), "vrmse_from_stats")
         return out
 
+    def band_power(self, spectrum, bin_start, point_index, nbins: int):
+        """spectrum complex64 [groups, points, nt]; CSR bins (int32 device tensors) -> [groups, nbins, nt] fp32 sums of |.|^2."""
+        if spectrum.dtype != torch.complex64 or not spectrum.is_cuda:
+            raise RuntimeError("band_power: spectrum must be a complex64 tensor on a HIP device (there is no CPU fallback)")
+        spectrum = spectrum.contiguous()
+        G, Pn, nt = (int(v) for v in spectrum.shape)
+        out = torch.zeros((G, nbins, nt), dtype=torch.float32, device=spectrum.device)
+        _lib.check(_lib.lib().pde_amd_band_power(torch.view_as_real(spectrum).data_ptr(), G, Pn, nt, bin_start.data_ptr(),
+                                                 point_index.data_ptr(), int(nbins), out.data_ptr(), _stream(spectrum)), "band_power")
+        return out
+
     @staticmethod
     def _term_array(terms: Sequence["_lib.Term"]):
         arr = (_lib.Term * len(terms))()

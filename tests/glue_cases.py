@@ -134,6 +134,23 @@ def check_metric_func(dev, tag):
             assert _rel(r.cpu().numpy(), want) <= 2e-5, (tag, mode, i, _rel(r.cpu().numpy(), want))
 
 
+def check_band_power(dev):
+    """The binning kernel alone on awkward shapes: frame counts that are no power of two or exceed one lane row, an
+    empty bin, a bin with a single member, bins longer than a workgroup; against a float64 sum."""
+    from pde_amd import reductions as R
+    rng = np.random.default_rng(5)
+    for G, Pn, nt, sizes in ((3, 50, 5, [0, 1, 7, 30]), (2, 2000, 70, [1500, 0, 300]), (1, 9, 1, [9])):
+        F = (rng.standard_normal((G, Pn, nt)) + 1j * rng.standard_normal((G, Pn, nt))).astype(np.complex64)
+        members = rng.permutation(Pn)[:sum(sizes)].astype(np.int32)
+        start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        got = R.get_backend().band_power(torch.from_numpy(F).to(dev), torch.from_numpy(start).to(dev),
+                                         torch.from_numpy(members).to(dev), len(sizes))
+        want = np.stack([(np.abs(F[:, members[start[i]:start[i + 1]]].astype(np.complex128)) ** 2).sum(axis=1)
+                         for i in range(len(sizes))], axis=1)
+        assert tuple(got.shape) == (G, len(sizes), nt)
+        assert np.allclose(got.cpu().numpy(), want, rtol=2e-6, atol=0), (G, Pn, nt)
+
+
 def check_gather(dev, transpose, spatial=(6, 8), C=18, chans=None):
     gen = torch.Generator().manual_seed(11)
     out = torch.randn(2, 3, *spatial, C, generator=gen)

@@ -28,6 +28,15 @@ class InterpReductions:
         r = np.sqrt(sel[:, R.S_D2].sum() / (n * len(valid)) + 1e-8)
         return torch.tensor([v, r], dtype=torch.float32)
 
+    def band_power(self, spectrum, bin_start, point_index, nbins):
+        F = spectrum.detach().cpu().numpy().astype(np.complex128)
+        bs, pi = bin_start.cpu().numpy().astype(np.int64), point_index.cpu().numpy().astype(np.int64)
+        out = np.zeros((F.shape[0], nbins, F.shape[2]))
+        for i in range(nbins):
+            members = pi[bs[i]:bs[i + 1]]
+            out[:, i] = (np.abs(F[:, members]) ** 2).sum(axis=1)
+        return torch.from_numpy(out.astype(np.float32)).to(spectrum.device)
+
     def pair_stats(self, pred, target, groups, rows, channels, rse_eps=1e-8):
         p = _np(pred).reshape(groups, rows, channels)
         g = _np(target).reshape(groups, rows, channels)

@@ -104,6 +104,10 @@ def test_accumulator_host_logic():
     GC.check_accumulator(CPU)
 
 
+def test_band_power_host_logic():
+    GC.check_band_power(CPU)
+
+
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_host_logic(tag):
     GC.check_metric_func(CPU, tag)

@@ -37,6 +37,10 @@ def test_accumulator():
     GC.check_accumulator(DEV)
 
 
+def test_band_power():
+    GC.check_band_power(DEV)
+
+
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_golden(tag):
     GC.check_metric_func(DEV, tag)

@@ -67,3 +67,21 @@ for shared, mode in ((False, "auto"), (True, "auto"), (True, "fused")):
     fn.backward_mode, fn.upstream_hint = mode, 1e-3
     ms = timeit(lambda: train_losses(shared))
     print(f"step losses (gather + TG residual + boundary strips) fwd+bwd, {'one shared gradient buffer' if shared else 'separate gradients added by autograd'}, backward_mode={mode}: {ms:.3f} ms")
+
+# metric_func's Fourier-band error: rocFFT + the binning kernel, against the same bins through index_add
+from pde_amd import metrics as PM
+mp = torch.randn(8, 128, 128, 21, 4, device=dev)
+mg = torch.randn(8, 128, 128, 21, 4, device=dev)
+ms = timeit(lambda: PM.metric_func(mp, mg, if_mean=True))
+print(f"metric_func [8,128,128,21,4] (all seven terms): {ms:.3f} ms")
+dF = torch.fft.fftn((mp - mg)[..., 1:, :].permute(0, 4, 1, 2, 3), dim=[2, 3]).reshape(32, 128 * 128, 20).contiguous()
+start, members, nbins = PM._radial_bins([128, 128], dev)
+ms = timeit(lambda: PM.R.get_backend().band_power(dF, start, members, nbins))
+binid = torch.repeat_interleave(torch.arange(nbins, device=dev), (start[1:] - start[:-1]).long())
+def via_index_add():
+    e2 = dF.abs() ** 2
+    acc = torch.zeros(32, nbins, 20, device=dev)
+    acc.index_add_(1, binid, e2[:, members.long()])
+    return acc
+ms2 = timeit(via_index_add)
+print(f"radial binning of |F|^2, [32,128x128,20] -> [32,{nbins},20]: band_power kernel {ms:.3f} ms, abs^2 + gather + index_add {ms2:.3f} ms")
