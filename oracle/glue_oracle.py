@@ -221,3 +221,46 @@ def fft_lp_loss(x, y, p=2, reduction="mean", flow=None, fhigh=None, eps=1e-20):
     d = torch.norm((xf - yf).reshape(n, -1), p, 1)
     r = d / (eps + torch.norm(yf.reshape(n, -1), p, 1))
     return r.mean() if reduction == "mean" else r.sum() if reduction == "sum" else r
+
+
+def rollout_evaluate(predict, data, t_input, valid_channels):
+    """tools/eval_rollout.py:93-146 as written there: per step the last output frame against the next true frame,
+    per-channel per-sample nRMSE, mean over the samples; the rollout's window is rebuilt with a cat per step."""
+    T_pred = data.shape[1] - t_input
+    one = {n: [] for _, n in valid_channels}
+    for t in range(T_pred):
+        out = predict(data[:, t:t + t_input])
+        for n, v in nrmse_per_channel(out[:, -1], data[:, t + t_input], valid_channels).items():
+            one[n].append(float(v.mean()))
+    roll = {n: [] for _, n in valid_channels}
+    cur = data[:, :t_input].clone()
+    for t in range(T_pred):
+        pred = predict(cur)[:, -1]
+        for n, v in nrmse_per_channel(pred, data[:, t_input + t], valid_channels).items():
+            roll[n].append(float(v.mean()))
+        cur = torch.cat([cur[:, 1:], pred.unsqueeze(1)], dim=1)
+    return one, roll
+
+
+def rollout_summary(one, roll):
+    """tools/eval_rollout.py:212-234"""
+    g = lambda v: float(np.exp(np.mean(np.log(np.asarray(v) + 1e-12))))
+    og, rg = {n: g(v) for n, v in one.items()}, {n: g(v) for n, v in roll.items()}
+    return {"one_step_gmean": og, "rollout_gmean": rg,
+            "one_step_overall": float(np.mean(list(og.values()))), "rollout_overall": float(np.mean(list(rg.values())))}
+
+
+def gt_scales_per_t(residual_batches, sites_per_sample):
+    """tools/compute_gt_scales_per_t.py:109-152 — residual_batches: per chunk a list of residual tensors [n, T_res, ...]
+    (one per equation, float64); sums of squares per frame over chunks, samples and space, divided by the number of
+    samples x lattice sites, square root; returned as float32 like the saved file."""
+    n_eq = len(residual_batches[0])
+    T_res = residual_batches[0][0].shape[1]
+    sums = torch.zeros(n_eq, T_res, dtype=torch.float64)
+    n = 0
+    for batch in residual_batches:
+        n += batch[0].shape[0]
+        for k, r in enumerate(batch):
+            for t in range(T_res):
+                sums[k, t] += torch.sum(r[:, t].double() ** 2).item()
+    return [torch.sqrt(sums[k] / (n * sites_per_sample)).float() for k in range(n_eq)]

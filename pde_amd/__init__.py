@@ -26,5 +26,7 @@ from .glue import (  # noqa: F401
     compute_pde_loss_burgers_3d, compute_pde_loss_heat_3d,
 )
 from .sink import shared_grad  # noqa: F401
+from .scales import ResidualScaleAccumulator  # noqa: F401
+from .rollout import evaluate_rollout, summarize_rollout, denormalised  # noqa: F401
 
 __version__ = "0.1.0"

@@ -257,17 +257,8 @@ class _ResidualLosses(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
-def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
-                    sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = (),
-                    mode: str = "auto"):
-    """-> (list of n_eqs + 1 scalar fp32 tensors: per-equation losses then their sum, sums[B, n_eqs] fp64).
-
-    loss_k = sum_{b, t, site} weights[k, t] * R_k(b, t, site)^2.
-    mode: 'recompute' (adjoint kernel re-evaluates the residuals; nothing is stored between forward and
-    backward), 'stored' (forward writes the residuals, backward reads them), 'auto', or ('fused', assumed): loss and
-    gradient of assumed * total in one pass at forward time when the fields need gradients (`assumed` is a device
-    scalar); backward hands the gradient out, rescaled on the device if the upstream value differs.
-    """
+def _prepare(prob, fields, weights, sparams, aux):
+    """Shape checks and fp32-contiguous copies shared by the entry points below."""
     s = SPECS[prob.spec]
     if len(fields) != len(s.fields) or len(sparams) != len(s.sparams) or len(aux) != len(s.aux):
         raise ValueError(f"{prob.spec}: expected {len(s.fields)} fields, {len(s.sparams)} per-sample parameters, {len(s.aux)} aux fields")
@@ -286,6 +277,31 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
         if tuple(x.shape) != (shape[0],) + tuple(shape[2:]):
             raise ValueError(f"{prob.spec}: auxiliary fields must be [B, *spatial], got {tuple(x.shape)}")
     w = weights.to(device=fs[0].device, dtype=torch.float32).contiguous()
+    return fs, sp, ax, w
+
+
+@torch.no_grad()
+def residual_fields(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
+                    sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = ()):
+    """The raw residual of every equation as [B, T_res, *spatial] fp32 tensors (zero outside the residual lattice),
+    written by the forward kernel; no autograd."""
+    fs, sp, ax, w = _prepare(prob, fields, weights, sparams, aux)
+    _, _, resid = _BACKEND.forward(prob, [f.detach() for f in fs], tuple(ax), tuple(sp), w, True)
+    return resid
+
+
+def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
+                    sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = (),
+                    mode: str = "auto"):
+    """-> (list of n_eqs + 1 scalar fp32 tensors: per-equation losses then their sum, sums[B, n_eqs] fp64).
+
+    loss_k = sum_{b, t, site} weights[k, t] * R_k(b, t, site)^2.
+    mode: 'recompute' (adjoint kernel re-evaluates the residuals; nothing is stored between forward and
+    backward), 'stored' (forward writes the residuals, backward reads them), 'auto', or ('fused', assumed): loss and
+    gradient of assumed * total in one pass at forward time when the fields need gradients (`assumed` is a device
+    scalar); backward hands the gradient out, rescaled on the device if the upstream value differs.
+    """
+    fs, sp, ax, w = _prepare(prob, fields, weights, sparams, aux)
     if not torch.is_grad_enabled():      # inside Function.forward the grad mode is always off, so it is passed in
         mode = ("nograd", mode)
     out = _ResidualLosses.apply(prob, tuple(ax), tuple(sp), w, mode, *fs)

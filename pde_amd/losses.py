@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functional import StencilProblem, residual_losses
+from .functional import StencilProblem, residual_fields, residual_losses
 from .stencil.specs import SPECS
 
 Tensor = torch.Tensor
@@ -150,6 +150,9 @@ class StencilPDELoss(nn.Module):
         T_res = T - spec.tlo - spec.thi
         n_sites = B * max(T_res, 0) * ext[0] * ext[1] * ext[2]
         wt, skipped = self._weights(T_res, n_sites, f0.device, t_offset)
+        if getattr(self, "_capture", None) is not None:      # residuals(): the fields themselves, no loss
+            self._capture.update(zip(self.EQS, residual_fields(prob, fields, wt, sparams, aux)))
+            self._capture["__sites_per_frame__"] = B * ext[0] * ext[1] * ext[2]
         mode = self.backward_mode
         if mode == "fused":
             hint = float(self.upstream_hint)
@@ -170,6 +173,17 @@ class StencilPDELoss(nn.Module):
         if self.TOTAL_KEY:
             losses["total"] = total
         return total, losses
+
+    @torch.no_grad()
+    def residuals(self, *args, **kwargs) -> Dict[str, Tensor]:
+        """The raw residual field of every equation for the inputs forward() takes: {equation: [B, T_res, *spatial]}
+        fp32 (zero outside the residual lattice), plus '__sites_per_frame__' = lattice sites per residual frame."""
+        self._capture = {}
+        try:
+            self.forward(*args, **kwargs)
+            return self._capture
+        finally:
+            self._capture = None
 
     def _buf(self, name, make, device):
         key = (name, str(device))

@@ -151,6 +151,107 @@ def check_band_power(dev):
         assert np.allclose(got.cpu().numpy(), want, rtol=2e-6, atol=0), (G, Pn, nt)
 
 
+def _toy_model(x):
+    """A stand-in for the network: each output frame mixes the two newest input frames, with a mild nonlinearity."""
+    nxt = 1.6 * x[:, -1] - 0.62 * x[:, -2] + 0.05 * torch.tanh(x[:, -1])
+    return torch.cat([x[:, 1:], nxt.unsqueeze(1)], dim=1)
+
+
+def check_rollout(dev):
+    """evaluate_rollout / summarize_rollout against the loop of tools/eval_rollout.py:93-146, :212-234 restated in
+    the oracle, on the same toy model and trajectories (float64 on the CPU there)."""
+    from pde_amd import rollout as PR
+    rng = np.random.default_rng(11)
+    M, T, H, W, C, t_in = 3, 9, 6, 8, 18, 4
+    base = np.cumsum(0.3 * rng.standard_normal((M, T, H, W, C)), axis=1) + 1.0
+    data = torch.tensor(base, dtype=torch.float32)
+    chans = [(0, "v0"), (1, "v1"), (5, "s2")]
+    want_one, want_roll = GO.rollout_evaluate(_toy_model, data.double(), t_in, chans)
+    one, roll = PR.evaluate_rollout(_toy_model, data, t_in, chans, device=dev)
+    for got, want in ((one, want_one), (roll, want_roll)):
+        assert list(got) == [n for _, n in chans]
+        for n in want:
+            assert len(got[n]) == T - t_in
+            assert _rel(got[n], want[n]) <= RTOL, (n, got[n], want[n])
+    s, ws = PR.summarize_rollout(one, roll), GO.rollout_summary(want_one, want_roll)
+    for k in ("one_step_overall", "rollout_overall"):
+        assert abs(s[k] - ws[k]) <= RTOL * abs(ws[k])
+    for k in ("one_step_gmean", "rollout_gmean"):
+        for n in ws[k]:
+            assert abs(s[k][n] - ws[k][n]) <= RTOL * abs(ws[k][n])
+    # the reference's calling convention of the model
+    class Net:
+        def __call__(self, x, return_normalized=False):
+            return (_toy_model(x) - 0.5) / 2.0, torch.tensor(0.5, device=x.device), torch.tensor(2.0, device=x.device)
+    one2, _ = PR.evaluate_rollout(PR.denormalised(Net()), data, t_in, chans, device=dev)
+    assert _rel(one2["v0"], want_one["v0"]) <= RTOL
+    try:
+        PR.evaluate_rollout(_toy_model, data[:, :t_in], t_in, chans, device=dev)
+        assert False, "no frame to predict must raise"
+    except ValueError:
+        pass
+
+
+def check_scale_accumulator(dev):
+    """ResidualScaleAccumulator against tools/compute_gt_scales_per_t.py:109-152 restated in the oracle, residuals
+    from the float64 oracle: Gray-Scott with the spectral Laplacian (the tool's own case) in two chunks of unequal
+    size, Taylor-Green with per-sample viscosity, and Rayleigh-Benard, whose lattice is cropped."""
+    import pde_amd
+    from pde_amd.scales import ResidualScaleAccumulator
+    from oracle import pde_oracle as PO
+    rng = np.random.default_rng(3)
+
+    def smooth(shape, amp=1.0):
+        x = rng.standard_normal(shape)
+        for ax in range(1, len(shape)):
+            x = x + np.roll(x, 1, ax) + np.roll(x, -1, ax)
+        return amp * x / 3.0 ** (len(shape) - 1)
+
+    # Gray-Scott, FFT Laplacian
+    kw = dict(dx=2.0 / 16, dy=2.0 / 16, dt=0.5, F=0.098, k=0.057, D_A=1.81e-3, D_B=1.39e-3)
+    A, B = 0.5 + 0.2 * smooth((5, 7, 16, 16)), 0.3 + 0.2 * smooth((5, 7, 16, 16))
+    fn = pde_amd.GrayScottPDELoss(nx=16, ny=16, **kw).to(dev)
+    acc = ResidualScaleAccumulator(fn)
+    batches = []
+    for sl in (slice(0, 3), slice(3, 5)):
+        acc.update(_t(A[sl], dev), _t(B[sl], dev))
+        batches.append(PO.residuals_gray_scott_fft(torch.tensor(A[sl]), torch.tensor(B[sl]), **kw))
+    res = acc.result()
+    want = GO.gt_scales_per_t(batches, 16 * 16)
+    assert list(res["eq_scales_per_t"]) == ["A_equation", "B_equation"]
+    for k, eq in enumerate(res["eq_scales_per_t"]):
+        got = res["eq_scales_per_t"][eq]
+        assert got.dtype == torch.float32 and tuple(got.shape) == (5,)
+        assert _rel(got.numpy(), want[k].numpy()) <= RTOL, (eq, got, want[k])
+        assert abs(res["eq_scales"][eq] - float(torch.sqrt((want[k].double() ** 2).mean()))) <= RTOL * res["eq_scales"][eq]
+
+    # Taylor-Green, per-sample nu
+    u, v, p = (smooth((2, 6, 8, 12)) for _ in range(3))
+    nu = np.array([0.02, 0.07])
+    kw = dict(dx=2 * np.pi / 12, dy=2 * np.pi / 8, dt=0.01)
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=12, ny=8, dt=0.01).to(dev)
+    acc = ResidualScaleAccumulator(fn)
+    acc.update(_t(u, dev), _t(v, dev), _t(p, dev), nu=_t(nu, dev))
+    res = acc.result()
+    want = GO.gt_scales_per_t([PO.residuals_tg2d(*(torch.tensor(x) for x in (u, v, p)), torch.tensor(nu), **kw)], 8 * 12)
+    for k, eq in enumerate(["continuity", "x_momentum", "y_momentum"]):
+        assert _rel(res["eq_scales_per_t"][eq].numpy(), want[k].numpy()) <= RTOL, eq
+
+    # Rayleigh-Benard: residual lattice cropped by skip_bl on the wall axis
+    fn = pde_amd.RayleighBenardFullPDELoss(nx=16, ny=12, skip_bl=2).to(dev)
+    ub, vb, bb = (smooth((2, 5, 16, 12)) for _ in range(3))
+    kap = np.array([1e-3, 4e-3])
+    acc = ResidualScaleAccumulator(fn)
+    acc.update(_t(ub, dev), _t(vb, dev), _t(bb, dev), kappa=_t(kap, dev))
+    res = acc.result()
+    pr = fn._params()
+    R = PO.residuals_rayleigh_benard(*(torch.tensor(x) for x in (ub, vb, bb)), torch.tensor(kap), dx=pr["dx"], dy=pr["dy"], dt=pr["dt"], skip_bl=2)
+    sites = int(np.prod(R[0].shape[2:]))
+    want = GO.gt_scales_per_t([R], sites)
+    for k, eq in enumerate(fn.EQS):
+        assert _rel(res["eq_scales_per_t"][eq].numpy(), want[k].numpy()) <= RTOL, eq
+
+
 def check_gather(dev, transpose, spatial=(6, 8), C=18, chans=None):
     gen = torch.Generator().manual_seed(11)
     out = torch.randn(2, 3, *spatial, C, generator=gen)

@@ -108,6 +108,14 @@ def test_band_power_host_logic():
     GC.check_band_power(CPU)
 
 
+def test_rollout_host_logic():
+    GC.check_rollout(CPU)
+
+
+def test_scale_accumulator_host_logic():
+    GC.check_scale_accumulator(CPU)
+
+
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_host_logic(tag):
     GC.check_metric_func(CPU, tag)

@@ -41,6 +41,14 @@ def test_band_power():
     GC.check_band_power(DEV)
 
 
+def test_rollout():
+    GC.check_rollout(DEV)
+
+
+def test_scale_accumulator():
+    GC.check_scale_accumulator(DEV)
+
+
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_golden(tag):
     GC.check_metric_func(DEV, tag)
