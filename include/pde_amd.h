@@ -205,6 +205,29 @@ int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int6
                                 const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
                                 float* grad_output, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The same four operations on a model output that is still normalised: the trainers compute
+ * `output = output_norm * std + mean` (finetune/train_taylor_green_2d_lora_v3.py:500-501, with mean and std one value
+ * per sample and channel, pretrain/model_v3.py:427-431) and evaluate every loss on that product; its forward and
+ * its autograd backward are two more passes each over the full 18-channel tensor.  Here `pred` / `output` is
+ * output_norm and scale[B][C] = std, shift[B][C] = mean (fp32, device): a value is read as
+ * fl(fl(x * scale) + shift), exactly what the product would hold in memory, and gradients come out w.r.t. output_norm
+ * (multiplied by scale).  `input` of the gather is raw data and is not mapped.  outer_per_sample = outer / B
+ * (the frames of a sample).  scale == shift == NULL gives the plain functions above. */
+int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                                 const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
+                                 const float* shift, int64_t outer_per_sample, double* sums, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int pde_amd_terms_backward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                                  const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
+                                  const float* shift, int64_t outer_per_sample, const float* scales, float* grad, void* stream);
+int pde_amd_gather_fields_affine(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
+                                 const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                                 const float* scale, const float* shift, float* const* fields, void* stream);
+int pde_amd_scatter_field_grads_affine(const float* const* field_grads, int64_t B, int64_t T_out, int64_t S, int32_t C,
+                                       const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                                       const float* scale, float* grad_output, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

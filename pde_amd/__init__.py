@@ -25,7 +25,7 @@ from .glue import (  # noqa: F401
     compute_pde_loss_rayleigh_benard, compute_pde_loss_shear_flow, compute_pde_loss_burgers_1d, compute_pde_loss_gray_scott,
     compute_pde_loss_burgers_3d, compute_pde_loss_heat_3d,
 )
-from .sink import shared_grad  # noqa: F401
+from .sink import shared_grad, Denormalised  # noqa: F401
 from .scales import ResidualScaleAccumulator  # noqa: F401
 from .rollout import evaluate_rollout, summarize_rollout, denormalised  # noqa: F401
 

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from . import reductions as R
-from .sink import sink_of
+from .sink import sink_of, unwrap
 
 CH_VX, CH_VY = 0, 1      # finetune/train_ns_incom_lora_v3.py:74-75
 
@@ -79,25 +79,25 @@ class _TermSums(torch.autograd.Function):
     """sums[t] = sum of squared term values, fp64 [n_terms]; differentiable w.r.t. pred."""
 
     @staticmethod
-    def forward(ctx, pred, target, ts: TermSet, outer: int, sink):
+    def forward(ctx, pred, target, ts: TermSet, outer: int, sink, affine):
         be = R.get_backend()
-        ctx.ts, ctx.outer, ctx.sink = ts, outer, sink
+        ctx.ts, ctx.outer, ctx.sink, ctx.affine = ts, outer, sink, affine
         ctx.save_for_backward(pred, target if target is not None else pred.new_empty(0))
         ctx.has_target = target is not None
-        return be.terms_forward(pred, target, outer, ts.dims, ts.terms, ts.indices(pred.device))
+        return be.terms_forward(pred, target, outer, ts.dims, ts.terms, ts.indices(pred.device), affine)
 
     @staticmethod
     def backward(ctx, gsums):
         pred, target = ctx.saved_tensors
         be = R.get_backend()
         args = (pred, target if ctx.has_target else None, ctx.outer, ctx.ts.dims, ctx.ts.terms,
-                ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous())
+                ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous(), ctx.affine)
         if ctx.sink is not None:      # added into the shared buffer of `pred` once that exists
             ctx.sink.terms.append(args)
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         grad = torch.zeros_like(pred)
         be.terms_backward(*args, grad)
-        return grad, None, None, None, None
+        return grad, None, None, None, None, None
 
 
 def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
@@ -108,10 +108,11 @@ def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
 
 def _term_means(pred, target, ts: TermSet, n_groups: int) -> List[torch.Tensor]:
     """mean of the squared term values of each group, as fp64 0-dim tensors (nan for an empty group, like torch.mean)."""
+    pred, affine = unwrap(pred)      # a Denormalised prediction: std and mean are applied inside the kernels
     pred = _prep(pred, "pred")
     target = _prep(target, "target") if target is not None else None
     outer = int(pred.shape[0]) * int(pred.shape[1])
-    sums = _TermSums.apply(pred, target, ts, outer, sink_of(pred))
+    sums = _TermSums.apply(pred, target, ts, outer, sink_of(pred), affine)
     out = []
     for g in range(n_groups):
         sel = [i for i, gg in enumerate(ts.groups) if gg == g]

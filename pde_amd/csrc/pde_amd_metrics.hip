@@ -134,9 +134,14 @@ struct TermArgs {
   long outer_stride;
   pde_amd_term t;
   long count;           // outer * n0 * n1 * n2 * nc
+  // optional per-(sample, channel) affine map of pred, [B][C] each: the tensor's value is pred * scale + shift
+  // (mul, then add, each rounded: what `output_norm * std + mean` leaves in memory); sample = outer index / outer_per_sample
+  const float* scale;
+  const float* shift;
+  long outer_per_sample;
 };
 
-__device__ __forceinline__ float term_value(const TermArgs& a, long e, long& off, long& tap_stride) {
+__device__ __forceinline__ float term_value(const TermArgs& a, long e, long& off, long& tap_stride, float& sc) {
   const pde_amd_term& t = a.t;
   const int ic = (int)(e % t.n[3]); e /= t.n[3];
   const int i2 = (int)(e % t.n[2]); e /= t.n[2];
@@ -145,10 +150,19 @@ __device__ __forceinline__ float term_value(const TermArgs& a, long e, long& off
   off = e * a.outer_stride + a.indices[t.idx_off[0] + i0] * a.stride[0] + a.indices[t.idx_off[1] + i1] * a.stride[1] +
         a.indices[t.idx_off[2] + i2] * a.stride[2] + a.indices[t.idx_off[3] + ic] * a.stride[3];
   tap_stride = a.stride[t.axis];
+  sc = 1.0f;
+  float sh = 0.0f;
+  if (a.scale) {
+    const long bc = (e / a.outer_per_sample) * a.stride[2] + a.indices[t.idx_off[3] + ic];      // stride[2] = C
+    sc = a.scale[bc];
+    sh = a.shift[bc];
+  }
   float v = 0.0f;
   for (int j = 0; j < t.n_taps; ++j) {
     const long o = off + t.shift[j] * tap_stride;
-    const float x = t.use_target ? a.pred[o] - a.target[o] : a.pred[o];
+    float p = a.pred[o];
+    if (a.scale) p = __fadd_rn(__fmul_rn(p, sc), sh);
+    const float x = t.use_target ? p - a.target[o] : p;
     v += t.coef[j] * x;
   }
   return v;
@@ -159,7 +173,8 @@ __global__ __launch_bounds__(256) void term_fwd_kernel(const TermArgs a, double*
   double acc = 0.0;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.count; e += (long)gridDim.x * 256) {
     long off, ts;
-    const float v = term_value(a, e, off, ts);
+    float sc;
+    const float v = term_value(a, e, off, ts, sc);
     acc += (double)(v * v);
   }
   acc = wave_sum_d(acc);
@@ -185,8 +200,9 @@ __global__ __launch_bounds__(256) void term_bwd_kernel(const TermArgs a, const f
   const float scale = 2.0f * scale_ptr[0];
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.count; e += (long)gridDim.x * 256) {
     long off, ts;
-    const float v = term_value(a, e, off, ts);
-    for (int j = 0; j < a.t.n_taps; ++j) grad[off + a.t.shift[j] * ts] += scale * v * a.t.coef[j];
+    float sc;
+    const float v = term_value(a, e, off, ts, sc);
+    for (int j = 0; j < a.t.n_taps; ++j) grad[off + a.t.shift[j] * ts] += scale * v * a.t.coef[j] * sc;
   }
 }
 
@@ -209,6 +225,10 @@ struct GatherArgs {
   int nf, C;
   long B, T_out, T_in, S;
   int rows, cols, transpose;   // S = lead * rows * cols; transpose swaps the last two spatial axes in the fields
+  // optional per-(sample, channel) affine map of `output`, [B][C] each: the gathered value is output * scale + shift
+  // (mul, then add, each rounded), the scattered gradient is multiplied by scale; `input` is taken as it is
+  const float* scale;
+  const float* shift;
 };
 
 __device__ __forceinline__ long field_site(const GatherArgs& a, long s) {
@@ -230,7 +250,11 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
     const long s = i % a.S, t = (i / a.S) % (a.T_out + 1), b = i / (a.S * (a.T_out + 1));
     const float* src = t == 0 ? a.input + ((b * a.T_in) * a.S + s) * a.C : a.output + ((b * a.T_out + (t - 1)) * a.S + s) * a.C;
     const long dst = (b * (a.T_out + 1) + t) * a.S + field_site(a, s);
-    for (int f = 0; f < a.nf; ++f) a.fields[f][dst] = src[a.ch[f]];
+    for (int f = 0; f < a.nf; ++f) {
+      float v = src[a.ch[f]];
+      if (a.scale && t > 0) v = __fadd_rn(__fmul_rn(v, a.scale[b * a.C + a.ch[f]]), a.shift[b * a.C + a.ch[f]]);
+      a.fields[f][dst] = v;
+    }
   }
 }
 
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const GatherArgs a, float*
       float r = 0.0f;
       for (int f = 0; f < a.nf; ++f)
         if ((unsigned)a.ch[f] == c) r += a.gfields[f][fbase + field_site(a, pt)];
+      if (a.scale) r *= a.scale[b * a.C + c];
       v[k] = r;
       if (++c == C) { c = 0; ++pt; }
     }
@@ -283,7 +308,12 @@ __global__ __launch_bounds__(TILE_PTS) void gather_tile_kernel(const GatherArgs 
     __syncthreads();
     if (tid < np) {
       const long dst = frame * a.S + field_site(a, p0 + tid);
-      for (int f = 0; f < a.nf; ++f) a.fields[f][dst] = tile[tid * C + (unsigned)a.ch[f]];
+      const bool affine = a.scale && t > 0;
+      for (int f = 0; f < a.nf; ++f) {
+        float v = tile[tid * C + (unsigned)a.ch[f]];
+        if (affine) v = __fadd_rn(__fmul_rn(v, a.scale[b * a.C + a.ch[f]]), a.shift[b * a.C + a.ch[f]]);
+        a.fields[f][dst] = v;
+      }
     }
     __syncthreads();
   }
@@ -304,6 +334,7 @@ __global__ __launch_bounds__(TILE_PTS) void scatter_tile_kernel(const GatherArgs
       const long src = (b * (a.T_out + 1) + t + 1) * a.S + field_site(a, p0 + tid);
       for (int f = 0; f < a.nf; ++f) {
         float v = a.gfields[f][src];
+        if (a.scale) v *= a.scale[b * a.C + a.ch[f]];
         bool again = false;      // a channel listed more than once collects all its gradients
         for (int g = 0; g < f; ++g) again = again || a.ch[g] == a.ch[f];
         if (again) v += tile[tid * C + (unsigned)a.ch[f]];
@@ -448,7 +479,10 @@ int pde_amd_band_power(const float* spectrum, int64_t groups, int64_t points, in
 }
 
 static int fill_term_args(TermArgs& a, const float* pred, const float* target, int64_t outer, const int32_t* dims,
-                          const pde_amd_term* t, const int32_t* indices) {
+                          const pde_amd_term* t, const int32_t* indices, const float* scale = nullptr,
+                          const float* shift = nullptr, int64_t outer_per_sample = 1) {
+  if ((scale == nullptr) != (shift == nullptr) || (scale && outer_per_sample < 1)) return PDE_AMD_EINVAL;
+  a.scale = scale; a.shift = shift; a.outer_per_sample = outer_per_sample;
   if (t->n_taps < 1 || t->n_taps > 3 || t->axis < 0 || t->axis > 2) return PDE_AMD_EINVAL;
   if (t->use_target && !target) return PDE_AMD_EINVAL;
   a.pred = pred; a.target = target; a.indices = indices; a.outer = outer;
@@ -470,6 +504,14 @@ size_t pde_amd_terms_workspace_bytes(int32_t n_terms) {
 int pde_amd_terms_forward(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                           const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, double* sums,
                           void* workspace, size_t workspace_bytes, void* stream) {
+  return pde_amd_terms_forward_affine(pred, target, outer, dims, terms, n_terms, indices, nullptr, nullptr, 1, sums, workspace,
+                                      workspace_bytes, stream);
+}
+
+int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                                 const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
+                                 const float* shift, int64_t outer_per_sample, double* sums, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   if (!pred || !dims || !terms || !sums || !indices || n_terms < 1 || n_terms > PDE_AMD_MAX_TERMS || outer < 0) return PDE_AMD_EINVAL;
   if (!workspace || workspace_bytes < pde_amd_terms_workspace_bytes(n_terms)) return PDE_AMD_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -479,7 +521,7 @@ int pde_amd_terms_forward(const float* pred, const float* target, int64_t outer,
   for (int k = 0; k <= PDE_AMD_MAX_TERMS; ++k) blk_start[k] = 0;
   for (int k = 0; k < n_terms; ++k) {
     TermArgs a;
-    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices);
+    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices, scale, shift, outer_per_sample);
     if (rc) return rc;
     const int nb = a.count > 0 ? term_blocks(a.count) : 0;
     blk_start[k + 1] = blk_start[k] + nb;
@@ -492,11 +534,17 @@ int pde_amd_terms_forward(const float* pred, const float* target, int64_t outer,
 int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                            const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scales,
                            float* grad, void* stream) {
+  return pde_amd_terms_backward_affine(pred, target, outer, dims, terms, n_terms, indices, nullptr, nullptr, 1, scales, grad, stream);
+}
+
+int pde_amd_terms_backward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
+                                  const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
+                                  const float* shift, int64_t outer_per_sample, const float* scales, float* grad, void* stream) {
   if (!pred || !dims || !terms || !scales || !grad || !indices || n_terms < 1 || n_terms > PDE_AMD_MAX_TERMS || outer < 0) return PDE_AMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   for (int k = 0; k < n_terms; ++k) {      // one launch per term, in order: terms may overlap each other, a term never overlaps itself
     TermArgs a;
-    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices);
+    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices, scale, shift, outer_per_sample);
     if (rc) return rc;
     if (a.count > 0) hipLaunchKernelGGL(term_bwd_kernel, dim3(term_blocks(a.count)), dim3(256), 0, st, a, scales + k, grad);
   }
@@ -509,6 +557,7 @@ static int fill_gather(GatherArgs& a, int64_t B, int64_t T_out, int64_t T_in, in
   if (transpose && (rows < 1 || cols < 1 || S % ((long)rows * cols) != 0)) return PDE_AMD_ESHAPE;
   a.nf = n_fields; a.C = C; a.B = B; a.T_out = T_out; a.T_in = T_in; a.S = S;
   a.rows = rows; a.cols = cols; a.transpose = transpose;
+  a.scale = a.shift = nullptr;
   for (int f = 0; f < n_fields; ++f) {
     if (channels[f] < 0 || channels[f] >= C) return PDE_AMD_EINVAL;
     a.ch[f] = channels[f];
@@ -519,9 +568,18 @@ static int fill_gather(GatherArgs& a, int64_t B, int64_t T_out, int64_t T_in, in
 int pde_amd_gather_fields(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
                           const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
                           float* const* fields, void* stream) {
+  return pde_amd_gather_fields_affine(output, input, B, T_out, T_in, S, C, channels, n_fields, rows, cols, transpose, nullptr, nullptr,
+                                      fields, stream);
+}
+
+int pde_amd_gather_fields_affine(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
+                                 const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                                 const float* scale, const float* shift, float* const* fields, void* stream) {
   GatherArgs a;
   const int rc = fill_gather(a, B, T_out, T_in, S, C, channels, n_fields, rows, cols, transpose);
   if (rc) return rc;
+  if ((scale == nullptr) != (shift == nullptr)) return PDE_AMD_EINVAL;
+  a.scale = scale; a.shift = shift;
   if (!output || !input || !fields) return PDE_AMD_EINVAL;
   a.output = output; a.input = input;
   for (int f = 0; f < n_fields; ++f) { if (!fields[f]) return PDE_AMD_EINVAL; a.fields[f] = fields[f]; }
@@ -542,9 +600,17 @@ int pde_amd_gather_fields(const float* output, const float* input, int64_t B, in
 int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int64_t T_out, int64_t S, int32_t C,
                                 const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
                                 float* grad_output, void* stream) {
+  return pde_amd_scatter_field_grads_affine(field_grads, B, T_out, S, C, channels, n_fields, rows, cols, transpose, nullptr,
+                                            grad_output, stream);
+}
+
+int pde_amd_scatter_field_grads_affine(const float* const* field_grads, int64_t B, int64_t T_out, int64_t S, int32_t C,
+                                       const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
+                                       const float* scale, float* grad_output, void* stream) {
   GatherArgs a;
   const int rc = fill_gather(a, B, T_out, 1, S, C, channels, n_fields, rows, cols, transpose);
   if (rc) return rc;
+  a.scale = scale;
   if (!field_grads || !grad_output) return PDE_AMD_EINVAL;
   for (int f = 0; f < n_fields; ++f) { if (!field_grads[f]) return PDE_AMD_EINVAL; a.gfields[f] = field_grads[f]; }
   const long n = B * T_out * S * (long)C;

@@ -18,7 +18,7 @@ import torch
 
 from . import losses as L
 from . import reductions as R
-from .sink import sink_of
+from .sink import sink_of, unwrap
 
 # channel layout of the 18-channel tensors, as the trainers name them
 CH_VX, CH_VY, CH_VZ = 0, 1, 2                       # finetune/train_burgers_3d_apebench_lora.py:76-78
@@ -29,9 +29,10 @@ CH_TRACER, CH_PRESS, CH_TEMP = 14, 15, 17            # finetune/train_shear_flow
 
 class _Gather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, output, input_data, channels, transpose, sink):
+    def forward(ctx, output, input_data, channels, transpose, sink, affine):
         ctx.channels, ctx.transpose, ctx.shape, ctx.sink = tuple(channels), bool(transpose), tuple(output.shape), sink
-        return tuple(R.get_backend().gather_fields(output, input_data, channels, transpose))
+        ctx.scale = affine[0] if affine is not None else None
+        return tuple(R.get_backend().gather_fields(output, input_data, channels, transpose, affine))
 
     @staticmethod
     def backward(ctx, *grads):
@@ -39,9 +40,9 @@ class _Gather(torch.autograd.Function):
         ref = next(g for g in gs if g is not None)
         gs = [g if g is not None else torch.zeros_like(ref) for g in gs]
         if ctx.sink is not None:      # the shared buffer of `output` is written once, after every loss has reported
-            ctx.sink.gathers.append((gs, ctx.channels, ctx.transpose))
-            return None, None, None, None, None
-        return R.get_backend().scatter_field_grads(gs, ctx.shape, ctx.channels, ctx.transpose), None, None, None, None
+            ctx.sink.gathers.append((gs, ctx.channels, ctx.transpose, ctx.scale))
+            return None, None, None, None, None, None
+        return R.get_backend().scatter_field_grads(gs, ctx.shape, ctx.channels, ctx.transpose, ctx.scale), None, None, None, None, None
 
 
 def gather_fields(output: torch.Tensor, input_data: torch.Tensor, channels: Sequence[int], transpose: bool = False):
@@ -49,11 +50,12 @@ def gather_fields(output: torch.Tensor, input_data: torch.Tensor, channels: Sequ
     taken from `input_data[:, 0]`.  transpose=True swaps the last two spatial axes (the Rayleigh-Benard trainer's
     `.transpose(-1, -2)`, finetune/train_rayleigh_benard_lora_v3.py:209-211).  Differentiable w.r.t. `output` only, as the
     trainers use it (their inputs carry no gradient)."""
+    output, affine = unwrap(output)      # a Denormalised output: std and mean are applied while gathering
     if output.shape[0] != input_data.shape[0] or output.shape[2:] != input_data.shape[2:]:
         raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Got {tuple(input_data.shape)} and {tuple(output.shape)}")
     out = output.float().contiguous()
     inp = input_data.detach().float().contiguous()
-    return list(_Gather.apply(out, inp, tuple(int(c) for c in channels), transpose, sink_of(out)))
+    return list(_Gather.apply(out, inp, tuple(int(c) for c in channels), transpose, sink_of(out), affine))
 
 
 def compute_pde_loss_taylor_green_2d(output, input_data, pde_loss_fn, nu, t_offset=None):

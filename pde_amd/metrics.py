@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import reductions as R
+from .sink import Denormalised
 from .boundary import valid_channels
 
 
@@ -31,6 +32,8 @@ def _flat(pred, target, n_lead: int):
 def compute_vrmse(output, target, channel_mask) -> Tuple[torch.Tensor, torch.Tensor]:
     """finetune/train_taylor_green_2d_lora_v3.py:204-232 — (vrmse, rmse) over the valid channels:
     rmse = sqrt(mse + 1e-8); vrmse = mean_c sqrt(mse_c / (var_c + 1e-8))."""
+    if isinstance(output, Denormalised):
+        output = output.materialise()
     ch = valid_channels(channel_mask)
     G, rows, C = _flat(output, target, 0)
     st = R.get_backend().pair_stats(output, target, 1, rows, C)[0]            # [C, NSTAT]

@@ -34,6 +34,18 @@ def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _affine_args(affine, outer: int):
+    """(scale pointer, shift pointer, outer indices per sample) of an optional (scale[B, C], shift[B, C]) pair"""
+    if affine is None:
+        return None, None, 1
+    scale, shift = affine
+    B = int(scale.shape[0])
+    if scale.dtype != torch.float32 or shift.dtype != torch.float32 or scale.shape != shift.shape or not scale.is_contiguous() \
+            or not shift.is_contiguous() or B < 1 or outer % B:
+        raise ValueError("affine map must be two contiguous fp32 [B, C] tensors with B dividing the outer extent")
+    return scale.data_ptr(), shift.data_ptr(), outer // B
+
+
 class HipReductions:
     name = "hip"
 
@@ -75,26 +87,29 @@ class HipReductions:
             arr[i] = t
         return arr
 
-    def terms_forward(self, pred, target, outer: int, dims: Sequence[int], terms, indices):
+    def terms_forward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, affine=None):
+        """affine = (scale[B, C], shift[B, C]) reads pred as pred * scale + shift per sample and channel."""
         l = _lib.lib()
         sums = torch.empty(len(terms), dtype=torch.float64, device=pred.device)
         nbytes = l.pde_amd_terms_workspace_bytes(len(terms))
         ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
         d = (C.c_int32 * 4)(*[int(v) for v in dims])
-        _lib.check(l.pde_amd_terms_forward(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
-                                           self._term_array(terms), len(terms), indices.data_ptr(), sums.data_ptr(),
-                                           ws.data_ptr(), nbytes, _stream(pred)), "terms_forward")
+        sc, sh, ops = _affine_args(affine, outer)
+        _lib.check(l.pde_amd_terms_forward_affine(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
+                                                  self._term_array(terms), len(terms), indices.data_ptr(), sc, sh, ops,
+                                                  sums.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "terms_forward")
         return sums
 
-    def terms_backward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, scales, grad):
+    def terms_backward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, scales, affine, grad):
         l = _lib.lib()
         d = (C.c_int32 * 4)(*[int(v) for v in dims])
-        _lib.check(l.pde_amd_terms_backward(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
-                                            self._term_array(terms), len(terms), indices.data_ptr(), scales.data_ptr(),
-                                            grad.data_ptr(), _stream(pred)), "terms_backward")
+        sc, sh, ops = _affine_args(affine, outer)
+        _lib.check(l.pde_amd_terms_backward_affine(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
+                                                   self._term_array(terms), len(terms), indices.data_ptr(), sc, sh, ops,
+                                                   scales.data_ptr(), grad.data_ptr(), _stream(pred)), "terms_backward")
         return grad
 
-    def gather_fields(self, output, input_data, channels: Sequence[int], transpose: bool) -> List[torch.Tensor]:
+    def gather_fields(self, output, input_data, channels: Sequence[int], transpose: bool, affine=None) -> List[torch.Tensor]:
         l = _lib.lib()
         B, T_out, T_in = output.shape[0], output.shape[1], input_data.shape[1]
         spatial = list(output.shape[2:-1])
@@ -106,12 +121,13 @@ class HipReductions:
         fshape = spatial[:-2] + [cols, rows] if transpose else spatial
         fields = [torch.empty([B, T_out + 1] + fshape, dtype=torch.float32, device=output.device) for _ in channels]
         ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
-        _lib.check(l.pde_amd_gather_fields(output.data_ptr(), input_data.data_ptr(), B, T_out, T_in, S, Cn, ch, len(channels),
-                                           rows, cols, int(bool(transpose)), _lib.ptr_array(fields, len(fields)), _stream(output)),
-                   "gather_fields")
+        sc, sh, _ = _affine_args(affine, B)
+        _lib.check(l.pde_amd_gather_fields_affine(output.data_ptr(), input_data.data_ptr(), B, T_out, T_in, S, Cn, ch, len(channels),
+                                                  rows, cols, int(bool(transpose)), sc, sh, _lib.ptr_array(fields, len(fields)),
+                                                  _stream(output)), "gather_fields")
         return fields
 
-    def scatter_field_grads(self, grads, out_shape, channels: Sequence[int], transpose: bool):
+    def scatter_field_grads(self, grads, out_shape, channels: Sequence[int], transpose: bool, scale=None):
         l = _lib.lib()
         B, T_out = out_shape[0], out_shape[1]
         spatial = list(out_shape[2:-1])
@@ -122,9 +138,9 @@ class HipReductions:
         rows, cols = (spatial[-2], spatial[-1]) if len(spatial) >= 2 else (1, 1)
         gout = torch.empty(list(out_shape), dtype=torch.float32, device=grads[0].device)
         ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
-        _lib.check(l.pde_amd_scatter_field_grads(_lib.ptr_array(grads, len(grads)), B, T_out, S, Cn, ch, len(channels),
-                                                 rows, cols, int(bool(transpose)), gout.data_ptr(), _stream(gout)),
-                   "scatter_field_grads")
+        _lib.check(l.pde_amd_scatter_field_grads_affine(_lib.ptr_array(grads, len(grads)), B, T_out, S, Cn, ch, len(channels),
+                                                        rows, cols, int(bool(transpose)), scale.data_ptr() if scale is not None else None,
+                                                        gout.data_ptr(), _stream(gout)), "scatter_field_grads")
         return gout
 
 

@@ -295,6 +295,68 @@ def check_compute_pde_loss(dev):
     assert abs(float(t2) - float(want.detach())) <= RTOL * float(want.detach())
 
 
+def check_denormalised(dev):
+    """Denormalised(output_norm, mean, std) against the trainers' `output = output_norm * std + mean` followed by the same
+    losses (finetune/train_taylor_green_2d_lora_v3.py:500-508): every loss value bit for bit (the kernels round the
+    product as the materialised tensor would hold it), the gradient w.r.t. output_norm to fp32 accuracy against
+    autograd through the materialised product, with and without the shared gradient buffer; Rayleigh-Benard's
+    transposed gather; misuse raises."""
+    import pde_amd
+    gen = torch.Generator().manual_seed(9)
+    B, T, H, W, C = 2, 4, 20, 16, 18
+    on0 = torch.randn(B, T, H, W, C, generator=gen).to(dev)
+    inp = torch.randn(B, 3, H, W, C, generator=gen).to(dev)
+    tgt = torch.randn(B, T, H, W, C, generator=gen).to(dev)
+    mean = (0.5 * torch.randn(B, 1, 1, 1, C, generator=gen)).to(dev)
+    std = (0.5 + torch.rand(B, 1, 1, 1, C, generator=gen)).to(dev)
+    mask = torch.zeros(B, C); mask[:, [0, 1, 15]] = 1
+    mask = mask.to(dev)
+    nu = torch.tensor([0.02, 0.07]).to(dev)
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=W, ny=H, dt=0.01).to(dev)
+    rb = pde_amd.RayleighBenardFullPDELoss(nx=H, ny=W, skip_bl=2).to(dev)
+
+    def losses(o):
+        pde, _ = PG.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)
+        rbl, _ = PG.compute_pde_loss_rayleigh_benard(o, inp, rb, nu)
+        bc = PB.compute_boundary_loss(o, tgt, mask, 2)
+        ns = PB.compute_noslip_loss(o)
+        seam = PB.compute_patch_boundary_loss(o, mask, patch_size=4)
+        return 1e-6 * pde + 1e-4 * rbl + 0.5 * bc + 0.25 * ns + 0.125 * seam, (pde, rbl, bc, ns, seam)
+
+    a = on0.clone().requires_grad_(True)
+    la, pa = losses(a * std + mean)
+    la.backward()
+    for share in (True, False):
+        b = on0.clone().requires_grad_(True)
+        den = pde_amd.Denormalised(b, mean, std, share=share)
+        assert tuple(den.shape) == (B, T, H, W, C) and den.dim() == 5
+        lb, pb = losses(den)
+        lb.backward()
+        for x, y in zip(pa, pb):
+            assert float(x.detach()) == float(y.detach()), (share, float(x.detach()), float(y.detach()))
+        assert _rel(b.grad.cpu().numpy(), a.grad.cpu().numpy()) <= 2e-6, share
+        assert np.array_equal((b.grad == 0).cpu().numpy(), (a.grad == 0).cpu().numpy())
+    # consumers outside the package take the materialised product; compute_vrmse does so by itself
+    den = pde_amd.Denormalised(on0, mean, std)
+    v1 = PM.compute_vrmse(den, tgt, mask)
+    v2 = PM.compute_vrmse(on0 * std + mean, tgt, mask)
+    assert float(v1[0]) == float(v2[0]) and float(v1[1]) == float(v2[1])
+    assert torch.equal(den.materialise(), on0 * std + mean)
+    # scalars and [C] vectors broadcast too; a per-frame std does not describe one value per sample and channel
+    d2 = pde_amd.Denormalised(on0, 0.25, torch.full((C,), 2.0).to(dev))
+    assert float(PB.compute_noslip_loss(d2)) == float(PB.compute_noslip_loss(on0 * 2.0 + 0.25))
+    try:
+        pde_amd.Denormalised(on0, mean, torch.ones(B, T, 1, 1, C).to(dev))
+        assert False, "per-frame std must raise"
+    except ValueError:
+        pass
+    try:
+        den + 1
+        assert False, "a Denormalised is not a tensor"
+    except TypeError:
+        pass
+
+
 def check_shared_grad(dev):
     """every loss of one training step on one tagged output: same values, and the gradient written through the shared buffer
     equals the sum autograd builds from the separate full-size gradients (up to the order of a few fp32 additions)"""

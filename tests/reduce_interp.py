@@ -59,9 +59,20 @@ class InterpReductions:
             off = (off[:, None] + np.asarray(lists[k], dtype=np.int64)[None, :] * strides[k]).reshape(-1)
         return off, strides[t.axis]
 
-    def _values(self, pred, target, outer, dims, t, pool):
+    @staticmethod
+    def _denorm(pred, outer, dims, affine):
+        """fp32 pred * scale + shift per (sample, channel), mul then add as torch does; [outer, n] float64"""
         n = dims[0] * dims[1] * dims[2] * dims[3]
-        x = _np(pred).reshape(outer, n)
+        x = pred.detach().cpu().float().reshape(outer, n // dims[3], dims[3])
+        if affine is not None:
+            sc, sh = (a.detach().cpu().float() for a in affine)
+            per = outer // sc.shape[0]
+            x = x * sc.repeat_interleave(per, 0)[:, None, :] + sh.repeat_interleave(per, 0)[:, None, :]
+        return x.double().numpy().reshape(outer, n)
+
+    def _values(self, pred, target, outer, dims, t, pool, affine=None):
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        x = self._denorm(pred, outer, dims, affine)
         if t.use_target:
             x = x - _np(target).reshape(outer, n)
         off, ts = self._term_offsets(dims, t, pool)
@@ -70,33 +81,44 @@ class InterpReductions:
             v += t.coef[j] * x[:, off + t.shift[j] * ts]
         return v, off, ts
 
-    def terms_forward(self, pred, target, outer, dims, terms, indices):
+    def terms_forward(self, pred, target, outer, dims, terms, indices, affine=None):
         pool = indices.cpu().numpy()
-        return torch.tensor([float((self._values(pred, target, outer, dims, t, pool)[0] ** 2).sum()) for t in terms],
+        return torch.tensor([float((self._values(pred, target, outer, dims, t, pool, affine)[0] ** 2).sum()) for t in terms],
                             dtype=torch.float64, device=pred.device)
 
-    def terms_backward(self, pred, target, outer, dims, terms, indices, scales, grad):
+    def terms_backward(self, pred, target, outer, dims, terms, indices, scales, affine, grad):
         pool = indices.cpu().numpy()
         n = dims[0] * dims[1] * dims[2] * dims[3]
         g = np.zeros((outer, n))
         sc = scales.detach().cpu().double().numpy()
         for k, t in enumerate(terms):
-            v, off, ts = self._values(pred, target, outer, dims, t, pool)
+            v, off, ts = self._values(pred, target, outer, dims, t, pool, affine)
             for j in range(t.n_taps):
                 np.add.at(g, (slice(None), off + t.shift[j] * ts), 2.0 * sc[k] * t.coef[j] * v)
+        if affine is not None:
+            per = outer // affine[0].shape[0]
+            g = (g.reshape(outer, n // dims[3], dims[3]) * _np(affine[0]).repeat(per, 0)[:, None, :]).reshape(outer, n)
         grad += torch.tensor(g.reshape(grad.shape), dtype=grad.dtype)
         return grad
 
-    def gather_fields(self, output, input_data, channels, transpose):
+    @staticmethod
+    def _bc(x, ndim):
+        return x.reshape((x.shape[0],) + (1,) * (ndim - 2) + (x.shape[1],))
+
+    def gather_fields(self, output, input_data, channels, transpose, affine=None):
+        if affine is not None:
+            output = output.float() * self._bc(affine[0], output.dim()) + self._bc(affine[1], output.dim())
         out = []
         for c in channels:
             f = torch.cat([input_data[:, 0:1, ..., c], output[..., c]], dim=1).float()
             out.append((f.transpose(-1, -2) if transpose else f).contiguous())
         return out
 
-    def scatter_field_grads(self, grads, out_shape, channels, transpose):
+    def scatter_field_grads(self, grads, out_shape, channels, transpose, scale=None):
         g = torch.zeros(out_shape, dtype=torch.float32)
         for c, gf in zip(channels, grads):
             gf = gf.transpose(-1, -2) if transpose else gf
             g[..., c] += gf[:, 1:]
+        if scale is not None:
+            g = g * self._bc(scale, g.dim())
         return g

@@ -108,6 +108,10 @@ def test_band_power_host_logic():
     GC.check_band_power(CPU)
 
 
+def test_denormalised_host_logic():
+    GC.check_denormalised(CPU)
+
+
 def test_rollout_host_logic():
     GC.check_rollout(CPU)
 

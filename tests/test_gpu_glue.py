@@ -41,6 +41,10 @@ def test_band_power():
     GC.check_band_power(DEV)
 
 
+def test_denormalised():
+    GC.check_denormalised(DEV)
+
+
 def test_rollout():
     GC.check_rollout(DEV)
 

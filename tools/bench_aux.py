@@ -68,6 +68,20 @@ for shared, mode in ((False, "auto"), (True, "auto"), (True, "fused")):
     ms = timeit(lambda: train_losses(shared))
     print(f"step losses (gather + TG residual + boundary strips) fwd+bwd, {'one shared gradient buffer' if shared else 'separate gradients added by autograd'}, backward_mode={mode}: {ms:.3f} ms")
 
+# the same step starting from the model's normalised output, as the trainers do (output = output_norm * std + mean first)
+mean_bc = torch.randn(B, 1, 1, 1, 18, device=dev)
+std_bc = torch.rand(B, 1, 1, 1, 18, device=dev) + 0.5
+def train_losses_from_norm(lazy):
+    o2.grad = None
+    o = pde_amd.Denormalised(o2, mean_bc, std_bc) if lazy else pde_amd.shared_grad(o2 * std_bc + mean_bc)
+    pde, _ = pde_amd.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)
+    bc_l = pde_amd.compute_boundary_loss(o, tgt, m2, 1)
+    (1e-3 * pde + 0.1 * bc_l).backward()
+fn.backward_mode, fn.upstream_hint = "fused", 1e-3
+for lazy in (False, True):
+    ms = timeit(lambda: train_losses_from_norm(lazy))
+    print(f"step losses from output_norm, {'Denormalised (std, mean applied inside the kernels)' if lazy else 'product materialised by torch, shared gradient buffer'}, backward_mode=fused: {ms:.3f} ms")
+
 # metric_func's Fourier-band error: rocFFT + the binning kernel, against the same bins through index_add
 from pde_amd import metrics as PM
 mp = torch.randn(8, 128, 128, 21, 4, device=dev)
