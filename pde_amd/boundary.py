@@ -51,6 +51,7 @@ class TermSet:
         self.pool: List[int] = []
         self.elems: List[int] = []                   # selected elements per outer index
         self._dev: Dict[torch.device, torch.Tensor] = {}
+        self._means: Dict[tuple, torch.Tensor] = {}      # group-mean matrices by (device, outer, groups)
 
     def add(self, lists: Sequence[Sequence[int]], group: int = 0, use_target: bool = True, axis: int = 0,
             taps: Sequence[Tuple[int, float]] = ((0, 1.0),)):
@@ -113,12 +114,22 @@ def _term_means(pred, target, ts: TermSet, n_groups: int) -> List[torch.Tensor]:
     target = _prep(target, "target") if target is not None else None
     outer = int(pred.shape[0]) * int(pred.shape[1])
     sums = _TermSums.apply(pred, target, ts, outer, sink_of(pred), affine)
+    counts = [outer * sum(ts.elems[i] for i, gg in enumerate(ts.groups) if gg == g) for g in range(n_groups)]
+    if all(c > 0 for c in counts):
+        # one small matrix product: means[g] = sum_i [term i in group g] / count_g * sums[i]
+        key = (pred.device, outer, n_groups)
+        m = ts._means.get(key)
+        if m is None:
+            m = torch.zeros(n_groups, len(ts.groups), dtype=torch.float64)
+            for i, g in enumerate(ts.groups):
+                m[g, i] = 1.0 / counts[g]
+            m = ts._means[key] = m.to(pred.device)
+        return list((m @ sums).unbind(0))
     out = []
     for g in range(n_groups):
         sel = [i for i, gg in enumerate(ts.groups) if gg == g]
-        cnt = outer * sum(ts.elems[i] for i in sel)
         tot = sums[sel].sum()
-        out.append(tot / cnt if cnt > 0 else tot * float("nan"))
+        out.append(tot / counts[g] if counts[g] > 0 else tot * float("nan"))
     return out
 
 

@@ -168,10 +168,28 @@ __device__ __forceinline__ float term_value(const TermArgs& a, long e, long& off
   return v;
 }
 
-__global__ __launch_bounds__(256) void term_fwd_kernel(const TermArgs a, double* __restrict__ partial) {
+struct BlockTable { int start[PDE_AMD_MAX_TERMS + 1]; };
+
+// every term of a set in ONE launch: block x belongs to the term whose block range holds it
+struct TermBatch {
+  TermArgs base;                       // everything but the term and its element count
+  pde_amd_term t[PDE_AMD_MAX_TERMS];
+  long count[PDE_AMD_MAX_TERMS];
+  BlockTable blk;
+  int n_terms;
+};
+
+__global__ __launch_bounds__(256) void term_fwd_batch_kernel(const TermBatch tb, double* __restrict__ partial) {
   __shared__ double s_red[4];
+  int k = 0;
+  while (k + 1 < tb.n_terms && (int)blockIdx.x >= tb.blk.start[k + 1]) ++k;
+  TermArgs a = tb.base;
+  a.t = tb.t[k];
+  a.count = tb.count[k];
+  const long first = (long)((int)blockIdx.x - tb.blk.start[k]) * 256 + threadIdx.x;
+  const long stride = (long)(tb.blk.start[k + 1] - tb.blk.start[k]) * 256;
   double acc = 0.0;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.count; e += (long)gridDim.x * 256) {
+  for (long e = first; e < a.count; e += stride) {
     long off, ts;
     float sc;
     const float v = term_value(a, e, off, ts, sc);
@@ -182,8 +200,6 @@ __global__ __launch_bounds__(256) void term_fwd_kernel(const TermArgs a, double*
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
-
-struct BlockTable { int start[PDE_AMD_MAX_TERMS + 1]; };
 
 // one wave per term: lanes stride over the term's block partials, then a shuffle tree (fixed order)
 __global__ __launch_bounds__(64) void term_finalize_kernel(const double* __restrict__ partial, const BlockTable blk, int n_terms, double* __restrict__ sums) {
@@ -516,18 +532,22 @@ int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t
   if (!workspace || workspace_bytes < pde_amd_terms_workspace_bytes(n_terms)) return PDE_AMD_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)workspace;
-  BlockTable blk;
-  int* blk_start = blk.start;
+  TermBatch tb;
+  tb.n_terms = n_terms;
+  int* blk_start = tb.blk.start;
   for (int k = 0; k <= PDE_AMD_MAX_TERMS; ++k) blk_start[k] = 0;
   for (int k = 0; k < n_terms; ++k) {
-    TermArgs a;
-    const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices, scale, shift, outer_per_sample);
+    const int rc = fill_term_args(tb.base, pred, target, outer, dims, &terms[k], indices, scale, shift, outer_per_sample);
     if (rc) return rc;
-    const int nb = a.count > 0 ? term_blocks(a.count) : 0;
+    tb.t[k] = terms[k];
+    tb.count[k] = tb.base.count;
+    const int nb = tb.base.count > 0 ? term_blocks(tb.base.count) : 0;
     blk_start[k + 1] = blk_start[k] + nb;
-    if (nb) hipLaunchKernelGGL(term_fwd_kernel, dim3(nb), dim3(256), 0, st, a, partial + blk_start[k]);
   }
-  hipLaunchKernelGGL(term_finalize_kernel, dim3((unsigned)n_terms), dim3(64), 0, st, partial, blk, (int)n_terms, sums);
+  for (int k = n_terms; k < PDE_AMD_MAX_TERMS; ++k) blk_start[k + 1] = blk_start[n_terms];
+  if (blk_start[n_terms] > 0)
+    hipLaunchKernelGGL(term_fwd_batch_kernel, dim3((unsigned)blk_start[n_terms]), dim3(256), 0, st, tb, partial);
+  hipLaunchKernelGGL(term_finalize_kernel, dim3((unsigned)n_terms), dim3(64), 0, st, partial, tb.blk, (int)n_terms, sums);
   return check_launch();
 }
 
