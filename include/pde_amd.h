@@ -220,7 +220,9 @@ int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t
                                  size_t workspace_bytes, void* stream);
 int pde_amd_terms_backward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                                   const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
-                                  const float* shift, int64_t outer_per_sample, const float* scales, float* grad, void* stream);
+                                  const float* shift, int64_t outer_per_sample, int32_t disjoint /* 1: the caller guarantees
+                                  that no two terms touch a common element of pred, and all terms run in one launch;
+                                  0: one launch per term, in order */, const float* scales, float* grad, void* stream);
 int pde_amd_gather_fields_affine(const float* output, const float* input, int64_t B, int64_t T_out, int64_t T_in, int64_t S, int32_t C,
                                  const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
                                  const float* scale, const float* shift, float* const* fields, void* stream);

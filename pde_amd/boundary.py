@@ -3,7 +3,7 @@
 Each function mirrors one reference helper (same name where the reference has one name per trainer the
 variant is spelled out).  They all reduce to sums of squares over a handful of "terms" (Cartesian
 products of index lists, one per slice the reference concatenates), evaluated by ONE forward launch
-per term set and differentiated by one launch per term; the tiny sqrt / mean epilogue is ordinary
+per term set and differentiated by one launch per term (one for the whole set where its terms touch no common element); the tiny sqrt / mean epilogue is ordinary
 torch on [n_terms] numbers, so autograd chains it.
 """
 from __future__ import annotations
@@ -51,7 +51,9 @@ class TermSet:
         self.pool: List[int] = []
         self.elems: List[int] = []                   # selected elements per outer index
         self._dev: Dict[torch.device, torch.Tensor] = {}
-        self._means: Dict[tuple, torch.Tensor] = {}      # group-mean matrices by (device, outer, groups)
+        self._means: Dict[tuple, torch.Tensor] = {}
+        self.foot: List[List[set]] = []
+        self.disjoint = True                         # no two terms touch a common element: their backward may run as one launch      # group-mean matrices by (device, outer, groups)
 
     def add(self, lists: Sequence[Sequence[int]], group: int = 0, use_target: bool = True, axis: int = 0,
             taps: Sequence[Tuple[int, float]] = ((0, 1.0),)):
@@ -66,6 +68,12 @@ class TermSet:
         for j, (s, c) in enumerate(taps):
             t.shift[j], t.coef[j] = int(s), float(c)
         t.use_target = int(use_target)
+        # elements of pred the term touches, per axis (the taps widen the list of their axis): two terms can only write the
+        # same gradient element if these sets meet on every axis
+        foot = [set(int(i) for i in lists[k]) for k in range(4)]
+        foot[axis] = {i + int(sh) for i in foot[axis] for sh, _ in taps}
+        self.disjoint = self.disjoint and all(any(not (foot[k] & other[k]) for k in range(4)) for other in self.foot)
+        self.foot.append(foot)
         self.terms.append(t)
         self.groups.append(group)
         self.elems.append(n)
@@ -92,7 +100,7 @@ class _TermSums(torch.autograd.Function):
         pred, target = ctx.saved_tensors
         be = R.get_backend()
         args = (pred, target if ctx.has_target else None, ctx.outer, ctx.ts.dims, ctx.ts.terms,
-                ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous(), ctx.affine)
+                ctx.ts.indices(pred.device), gsums.to(torch.float32).contiguous(), ctx.affine, ctx.ts.disjoint)
         if ctx.sink is not None:      # added into the shared buffer of `pred` once that exists
             ctx.sink.terms.append(args)
             return None, None, None, None, None, None

@@ -211,6 +211,24 @@ __global__ __launch_bounds__(64) void term_finalize_kernel(const double* __restr
   if (threadIdx.x == 0) sums[t] = r;
 }
 
+// the backward of every term of a set in one launch, for sets whose terms touch no common element
+__global__ __launch_bounds__(256) void term_bwd_batch_kernel(const TermBatch tb, const float* __restrict__ scales, float* __restrict__ grad) {
+  int k = 0;
+  while (k + 1 < tb.n_terms && (int)blockIdx.x >= tb.blk.start[k + 1]) ++k;
+  TermArgs a = tb.base;
+  a.t = tb.t[k];
+  a.count = tb.count[k];
+  const float scale = 2.0f * scales[k];
+  const long first = (long)((int)blockIdx.x - tb.blk.start[k]) * 256 + threadIdx.x;
+  const long stride = (long)(tb.blk.start[k + 1] - tb.blk.start[k]) * 256;
+  for (long e = first; e < a.count; e += stride) {
+    long off, ts;
+    float sc;
+    const float v = term_value(a, e, off, ts, sc);
+    for (int j = 0; j < a.t.n_taps; ++j) grad[off + a.t.shift[j] * ts] += scale * v * a.t.coef[j] * sc;
+  }
+}
+
 // grad[...] += scale * 2 * value * coef_j at every tap; offsets inside one term never collide
 __global__ __launch_bounds__(256) void term_bwd_kernel(const TermArgs a, const float* __restrict__ scale_ptr, float* __restrict__ grad) {
   const float scale = 2.0f * scale_ptr[0];
@@ -554,14 +572,32 @@ int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t
 int pde_amd_terms_backward(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                            const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scales,
                            float* grad, void* stream) {
-  return pde_amd_terms_backward_affine(pred, target, outer, dims, terms, n_terms, indices, nullptr, nullptr, 1, scales, grad, stream);
+  return pde_amd_terms_backward_affine(pred, target, outer, dims, terms, n_terms, indices, nullptr, nullptr, 1, 0, scales, grad, stream);
 }
 
 int pde_amd_terms_backward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                                   const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
-                                  const float* shift, int64_t outer_per_sample, const float* scales, float* grad, void* stream) {
+                                  const float* shift, int64_t outer_per_sample, int32_t disjoint, const float* scales,
+                                  float* grad, void* stream) {
   if (!pred || !dims || !terms || !scales || !grad || !indices || n_terms < 1 || n_terms > PDE_AMD_MAX_TERMS || outer < 0) return PDE_AMD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (disjoint && n_terms > 1) {
+    TermBatch tb;
+    tb.n_terms = n_terms;
+    int* blk_start = tb.blk.start;
+    blk_start[0] = 0;
+    for (int k = 0; k < n_terms; ++k) {
+      const int rc = fill_term_args(tb.base, pred, target, outer, dims, &terms[k], indices, scale, shift, outer_per_sample);
+      if (rc) return rc;
+      tb.t[k] = terms[k];
+      tb.count[k] = tb.base.count;
+      blk_start[k + 1] = blk_start[k] + (tb.base.count > 0 ? term_blocks(tb.base.count) : 0);
+    }
+    for (int k = n_terms; k < PDE_AMD_MAX_TERMS; ++k) blk_start[k + 1] = blk_start[n_terms];
+    if (blk_start[n_terms] > 0)
+      hipLaunchKernelGGL(term_bwd_batch_kernel, dim3((unsigned)blk_start[n_terms]), dim3(256), 0, st, tb, scales, grad);
+    return check_launch();
+  }
   for (int k = 0; k < n_terms; ++k) {      // one launch per term, in order: terms may overlap each other, a term never overlaps itself
     TermArgs a;
     const int rc = fill_term_args(a, pred, target, outer, dims, &terms[k], indices, scale, shift, outer_per_sample);

@@ -100,13 +100,14 @@ class HipReductions:
                                                   sums.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "terms_forward")
         return sums
 
-    def terms_backward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, scales, affine, grad):
+    def terms_backward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, scales, affine, disjoint, grad):
+        """grad += d(sum_k scales[k] * sums[k]) / d pred; disjoint=True promises that no two terms touch a common element."""
         l = _lib.lib()
         d = (C.c_int32 * 4)(*[int(v) for v in dims])
         sc, sh, ops = _affine_args(affine, outer)
         _lib.check(l.pde_amd_terms_backward_affine(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
                                                    self._term_array(terms), len(terms), indices.data_ptr(), sc, sh, ops,
-                                                   scales.data_ptr(), grad.data_ptr(), _stream(pred)), "terms_backward")
+                                                   int(bool(disjoint)), scales.data_ptr(), grad.data_ptr(), _stream(pred)), "terms_backward")
         return grad
 
     def gather_fields(self, output, input_data, channels: Sequence[int], transpose: bool, affine=None) -> List[torch.Tensor]:

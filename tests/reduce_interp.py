@@ -86,7 +86,7 @@ class InterpReductions:
         return torch.tensor([float((self._values(pred, target, outer, dims, t, pool, affine)[0] ** 2).sum()) for t in terms],
                             dtype=torch.float64, device=pred.device)
 
-    def terms_backward(self, pred, target, outer, dims, terms, indices, scales, affine, grad):
+    def terms_backward(self, pred, target, outer, dims, terms, indices, scales, affine, disjoint, grad):
         pool = indices.cpu().numpy()
         n = dims[0] * dims[1] * dims[2] * dims[3]
         g = np.zeros((outer, n))
