@@ -214,6 +214,10 @@ int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int6
  * fl(fl(x * scale) + shift), exactly what the product would hold in memory, and gradients come out w.r.t. output_norm
  * (multiplied by scale).  `input` of the gather is raw data and is not mapped.  outer_per_sample = outer / B
  * (the frames of a sample).  scale == shift == NULL gives the plain functions above. */
+/* pde_amd_pair_stats with pred read as pred * scale + shift, scale and shift [groups][channels]: a group per sample. */
+int pde_amd_pair_stats_affine(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
+                              float rse_eps, const float* scale, const float* shift, double* stats, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                                  const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
                                  const float* shift, int64_t outer_per_sample, double* sums, void* workspace,

@@ -27,10 +27,14 @@ constexpr int PS_UNROLL = 4;
 
 __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                            long rows, int C, int rows_per_step, long steps_per_block,
-                                                           int blocks_per_group, float rse_eps, double* __restrict__ partial) {
+                                                           int blocks_per_group, float rse_eps, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, double* __restrict__ partial) {
   extern __shared__ double s_acc[];          // [NSTAT][NT]
   const int NT = blockDim.x;
   const int g = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
+  // optional affine map of pred, one (scale, shift) per group and channel: pred is read as fl(fl(p * scale) + shift)
+  const bool affine = scale != nullptr;
+  const float sc = affine ? scale[(long)g * C + threadIdx.x % C] : 1.0f, sh = affine ? shift[(long)g * C + threadIdx.x % C] : 0.0f;
   const long n = rows * (long)C;             // elements of the group
   const float* p = pred + (long)g * n;
   const float* q = target + (long)g * n;
@@ -43,6 +47,10 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
     float pv[PS_UNROLL], gv[PS_UNROLL];
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) { pv[u] = p[i + (long)u * NT]; gv[u] = q[i + (long)u * NT]; }
+    if (affine) {
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) pv[u] = __fadd_rn(__fmul_rn(pv[u], sc), sh);
+    }
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
       const float d = pv[u] - gv[u];
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
     }
   }
   for (; i < last; i += NT) {
-    const float pvv = p[i], gvv = q[i];
+    const float pvv = affine ? __fadd_rn(__fmul_rn(p[i], sc), sh) : p[i], gvv = q[i];
     const float d = pvv - gvv;
     const float d2 = d * d, g2 = gvv * gvv;
     a0 += (double)d2; a1 += (double)g2; a2 += (double)gvv; a3 += (double)pvv;
@@ -467,6 +475,13 @@ size_t pde_amd_pair_stats_workspace_bytes(int64_t groups, int64_t rows, int32_t 
 
 int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
                        float rse_eps, double* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  return pde_amd_pair_stats_affine(pred, target, groups, rows, channels, rse_eps, nullptr, nullptr, stats, workspace, workspace_bytes, stream);
+}
+
+int pde_amd_pair_stats_affine(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
+                              float rse_eps, const float* scale, const float* shift, double* stats, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if ((scale == nullptr) != (shift == nullptr)) return PDE_AMD_EINVAL;
   if (groups == 0 || rows == 0) {
     if (groups < 0 || rows < 0 || channels <= 0) return PDE_AMD_EINVAL;
     if (groups > 0 && stats) (void)hipMemsetAsync(stats, 0, (size_t)groups * channels * NSTAT * sizeof(double), (hipStream_t)stream);
@@ -480,7 +495,7 @@ int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, i
   double* partial = (double*)workspace;
   const size_t lds = (size_t)NSTAT * pl.nt * sizeof(double);
   hipLaunchKernelGGL(pair_stats_kernel, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
-                     (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, partial);
+                     (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial);
   hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)((NSTAT * channels + 3) / 4), (unsigned)groups), dim3(256), 0, st, partial,
                      pl.blocks_per_group, (int)channels, stats);
   return check_launch();

@@ -32,11 +32,15 @@ def _flat(pred, target, n_lead: int):
 def compute_vrmse(output, target, channel_mask) -> Tuple[torch.Tensor, torch.Tensor]:
     """finetune/train_taylor_green_2d_lora_v3.py:204-232 — (vrmse, rmse) over the valid channels:
     rmse = sqrt(mse + 1e-8); vrmse = mean_c sqrt(mse_c / (var_c + 1e-8))."""
-    if isinstance(output, Denormalised):
-        output = output.materialise()
     ch = valid_channels(channel_mask)
     G, rows, C = _flat(output, target, 0)
-    st = R.get_backend().pair_stats(output, target, 1, rows, C)[0]            # [C, NSTAT]
+    if isinstance(output, Denormalised):
+        # one group per sample, std and mean applied while reading; the groups' sums are then added
+        B = int(output.shape[0])
+        per = R.get_backend().pair_stats(output.base.detach(), target, B, rows // B, C, affine=(output.scale, output.shift))
+        st = per.sum(0)
+    else:
+        st = R.get_backend().pair_stats(output, target, 1, rows, C)[0]        # [C, NSTAT]
     if len(ch) <= 64:      # one tiny launch instead of a dozen element-wise ones
         out = R.get_backend().vrmse_from_stats(st, ch, rows)
         return out[0], out[1]

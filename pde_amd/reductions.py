@@ -49,7 +49,8 @@ def _affine_args(affine, outer: int):
 class HipReductions:
     name = "hip"
 
-    def pair_stats(self, pred, target, groups: int, rows: int, channels: int, rse_eps: float = 1e-8):
+    def pair_stats(self, pred, target, groups: int, rows: int, channels: int, rse_eps: float = 1e-8, affine=None):
+        """affine = (scale, shift), each [groups, channels]: pred is read as pred * scale + shift."""
         l = _lib.lib()
         pred, target = _f32c(pred, "pred"), _f32c(target, "target")
         if pred.numel() != groups * rows * channels or target.numel() != pred.numel():
@@ -57,8 +58,11 @@ class HipReductions:
         stats = torch.empty((groups, channels, NSTAT), dtype=torch.float64, device=pred.device)
         nbytes = l.pde_amd_pair_stats_workspace_bytes(groups, rows, channels)
         ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
-        _lib.check(l.pde_amd_pair_stats(pred.data_ptr(), target.data_ptr(), groups, rows, channels, float(rse_eps),
-                                        stats.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "pair_stats")
+        sc, sh, _ = _affine_args(affine, groups)
+        if affine is not None and tuple(affine[0].shape) != (groups, channels):
+            raise ValueError(f"pair_stats: the affine map must be [{groups}, {channels}], got {tuple(affine[0].shape)}")
+        _lib.check(l.pde_amd_pair_stats_affine(pred.data_ptr(), target.data_ptr(), groups, rows, channels, float(rse_eps), sc, sh,
+                                               stats.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "pair_stats")
         return stats
 
     def vrmse_from_stats(self, stats, valid: Sequence[int], rows: int):

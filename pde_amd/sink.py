@@ -105,6 +105,9 @@ class Denormalised:
     def dim(self) -> int:
         return self.base.dim()
 
+    def numel(self) -> int:
+        return self.base.numel()
+
     def materialise(self) -> torch.Tensor:
         """the product as an ordinary (differentiable) tensor, for consumers outside this package"""
         return self._raw * self._std + self._mean

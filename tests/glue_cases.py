@@ -336,11 +336,12 @@ def check_denormalised(dev):
             assert float(x.detach()) == float(y.detach()), (share, float(x.detach()), float(y.detach()))
         assert _rel(b.grad.cpu().numpy(), a.grad.cpu().numpy()) <= 2e-6, share
         assert np.array_equal((b.grad == 0).cpu().numpy(), (a.grad == 0).cpu().numpy())
-    # consumers outside the package take the materialised product; compute_vrmse does so by itself
+    # compute_vrmse applies std and mean while reading (per-sample groups, so only the order of the fp64 sums differs);
+    # consumers outside the package take the materialised product
     den = pde_amd.Denormalised(on0, mean, std)
     v1 = PM.compute_vrmse(den, tgt, mask)
     v2 = PM.compute_vrmse(on0 * std + mean, tgt, mask)
-    assert float(v1[0]) == float(v2[0]) and float(v1[1]) == float(v2[1])
+    assert abs(float(v1[0]) - float(v2[0])) <= 1e-6 * float(v2[0]) and abs(float(v1[1]) - float(v2[1])) <= 1e-6 * float(v2[1])
     assert torch.equal(den.materialise(), on0 * std + mean)
     # scalars and [C] vectors broadcast too; a per-frame std does not describe one value per sample and channel
     d2 = pde_amd.Denormalised(on0, 0.25, torch.full((C,), 2.0).to(dev))

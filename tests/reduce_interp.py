@@ -37,7 +37,9 @@ class InterpReductions:
             out[:, i] = (np.abs(F[:, members]) ** 2).sum(axis=1)
         return torch.from_numpy(out.astype(np.float32)).to(spectrum.device)
 
-    def pair_stats(self, pred, target, groups, rows, channels, rse_eps=1e-8):
+    def pair_stats(self, pred, target, groups, rows, channels, rse_eps=1e-8, affine=None):
+        if affine is not None:      # fp32 mul, then add, as torch does
+            pred = pred.detach().float().reshape(groups, rows, channels) * affine[0][:, None, :] + affine[1][:, None, :]
         p = _np(pred).reshape(groups, rows, channels)
         g = _np(target).reshape(groups, rows, channels)
         d = p - g

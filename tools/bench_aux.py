@@ -82,6 +82,17 @@ for lazy in (False, True):
     ms = timeit(lambda: train_losses_from_norm(lazy))
     print(f"step losses from output_norm, {'Denormalised (std, mean applied inside the kernels)' if lazy else 'product materialised by torch, shared gradient buffer'}, backward_mode=fused: {ms:.3f} ms")
 
+# a validation batch from the normalised output (finetune/train_taylor_green_2d_lora_v3.py:263-269): boundary RMSE, residual loss, VRMSE
+def validate_from_norm(lazy):
+    with torch.no_grad():
+        o = pde_amd.Denormalised(o2, mean_bc, std_bc) if lazy else o2 * std_bc + mean_bc
+        bc_l = pde_amd.compute_boundary_loss(o, tgt, m2, 1)
+        pde, _ = pde_amd.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)
+        v, r = pde_amd.compute_vrmse(o, tgt, m2)
+for lazy in (False, True):
+    ms = timeit(lambda: validate_from_norm(lazy))
+    print(f"validation scalars from output_norm, {'Denormalised' if lazy else 'product materialised by torch'}: {ms:.3f} ms")
+
 # metric_func's Fourier-band error: rocFFT + the binning kernel, against the same bins through index_add
 from pde_amd import metrics as PM
 mp = torch.randn(8, 128, 128, 21, 4, device=dev)
