@@ -71,8 +71,24 @@ def cpu_baseline(seconds=12.0):
             best = min(best, dt)
         if time.perf_counter() - start > seconds and n >= 3:
             break
-    return {"value": pts / best, "unit": "grid-points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle TaylorGreen2D fwd+bwd fp32, B={bs} T={T} {H}x{W}, best of {n - 1} after warm-up"}
+    # the same sample on one thread (a few passes only)
+    threads = torch.get_num_threads()
+    one = float("inf")
+    try:
+        torch.set_num_threads(1)
+        for i in range(3):
+            for f in fields:
+                f.grad = None
+            t0 = time.perf_counter()
+            total, _ = fn(*fields, nu=nu)
+            total.backward()
+            if i:
+                one = min(one, time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(threads)
+    return {"value": pts / best, "unit": "grid-points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle TaylorGreen2D fwd+bwd fp32, B={bs} T={T} {H}x{W}, best of {n - 1} after warm-up",
+            "one_thread_value": pts / one}
 
 
 def measured_traffic(kernel_substr):
