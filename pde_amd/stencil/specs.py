@@ -293,7 +293,8 @@ def _burgers2d_ch():
     ru = _ddt(b, u) + conv(u) - u * div - nu * lap(u)
     rv = _ddt(b, v) + conv(v) - v * div - nu * lap(v)
     irr = _d1c4(b, v, 2, "dx") - _d1c4(b, u, 1, "dy")
-    return b.done([ru, rv, irr], quad_width_bwd=2, quad_prefetch=1)
+    # adjoint: 171 VGPR at 2 points per lane; a 16 x 32 tile on 4 waves lets two workgroups share a CU (8 waves on 16 x 64 left room for one)
+    return b.done([ru, rv, irr], quad_width_bwd=2, quad_prefetch=1, quad_bwd=(1, 16, 32), threads_quad_bwd=128)
 
 
 def _active_matter():
