@@ -1109,6 +1109,17 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
   msg.init(o0, o1, o2, g);
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) msg.fetch(k, rp[k] + (long)trc * g.S);
+  MultiStage<TGT, P::PER0, P::PER1, P::PER2, NT, W, GT_ON ? NGT * P::NE : 1> msgt;
+  if (GT_ON) {
+    msgt.init(o0, o1, o2, g);
+#pragma unroll
+    for (int s = 0; s < NGT; ++s) {
+      const int ot = s < P::GTLO ? s - P::GTLO : s - P::GTLO + 1;
+      const int trs = max(min(tr0 + ot, g.TR - 1), 0);
+#pragma unroll
+      for (int k = 0; k < P::NE; ++k) msgt.fetch(s * P::NE + k, rp[k] + (long)trs * g.S);
+    }
+  }
   MultiStage<TA, P::PER0, P::PER1, P::PER2, NT, W, AF_ON ? P::NF : 1> msa;
   if (AF_ON) {
     msa.init(o0, o1, o2, g);
@@ -1149,9 +1160,7 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
 #pragma unroll
       for (int k = 0; k < P::NE; ++k) {
         const float cfk = cf[ot + P::GTLO][k];
-        float* dst = s_gt + (s * P::NE + k) * TGT::SIZE;
-        if (cfk != 0.0f) stage_tile<TGT, P::PER0, P::PER1, P::PER2, NT, W>(dst, rp[k] + (long)(tr0 + ot) * g.S, o0, o1, o2, g, cfk);
-        else zero_tile_q<TGT, NT, W>(dst);
+        msgt.store(s * P::NE + k, s_gt + (s * P::NE + k) * TGT::SIZE, cfk, cfk != 0.0f);
       }
     }
   }
