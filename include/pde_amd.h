@@ -124,6 +124,7 @@ int pde_amd_rescale_gradients(float* const* grads, int32_t n_fields, int64_t ele
  * whatever leading axes the caller wants separate results for: samples, samples x frames, or 1).  For every
  * (group, channel) it returns PDE_AMD_NSTAT fp64 numbers:
  *   [0] sum (p-g)^2   [1] sum g^2   [2] sum g   [3] sum p   [4] sum (p-g)^2 / (g^2 + rse_eps)   [5] max |p-g|
+ *   ([4] is left 0 when rse_eps < 0: its division is the costliest part of the pass and only compute_mean_rse reads it)
  * from which the host forms, with the reference's own epsilons,
  *   compute_vrmse            finetune/train_taylor_green_2d_lora_v3.py:204-232 (per-channel mse, variance of g, overall rmse)
  *   evaluate() accumulators  eval/eval_nrmse.py:125-155 (per channel and per frame sums of (p-g)^2 and g^2)

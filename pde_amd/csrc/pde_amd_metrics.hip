@@ -25,6 +25,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ------------------------------------------------------------------------------------------------
 constexpr int PS_UNROLL = 4;
 
+template <bool RSE>
 __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                            long rows, int C, int rows_per_step, long steps_per_block,
                                                            int blocks_per_group, float rse_eps, const float* __restrict__ scale,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
       const float d = pv[u] - gv[u];
       const float d2 = d * d, g2 = gv[u] * gv[u];
       a0 += (double)d2; a1 += (double)g2; a2 += (double)gv[u]; a3 += (double)pv[u];
-      a4 += (double)(d2 / (g2 + rse_eps));
+      if (RSE) a4 += (double)(d2 / (g2 + rse_eps));
       amax = fmaxf(amax, fabsf(d));
     }
   }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
     const float d = pvv - gvv;
     const float d2 = d * d, g2 = gvv * gvv;
     a0 += (double)d2; a1 += (double)g2; a2 += (double)gvv; a3 += (double)pvv;
-    a4 += (double)(d2 / (g2 + rse_eps));
+    if (RSE) a4 += (double)(d2 / (g2 + rse_eps));
     amax = fmaxf(amax, fabsf(d));
   }
   s_acc[0 * NT + threadIdx.x] = a0;
@@ -494,8 +495,13 @@ int pde_amd_pair_stats_affine(const float* pred, const float* target, int64_t gr
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)workspace;
   const size_t lds = (size_t)NSTAT * pl.nt * sizeof(double);
-  hipLaunchKernelGGL(pair_stats_kernel, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
-                     (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial);
+  // a negative rse_eps leaves the relative-squared-error statistic out (0): its division is a fifth of the kernel's arithmetic
+  if (rse_eps >= 0.0f)
+    hipLaunchKernelGGL(pair_stats_kernel<true>, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
+                       (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial);
+  else
+    hipLaunchKernelGGL(pair_stats_kernel<false>, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
+                       (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial);
   hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)((NSTAT * channels + 3) / 4), (unsigned)groups), dim3(256), 0, st, partial,
                      pl.blocks_per_group, (int)channels, stats);
   return check_launch();

@@ -49,8 +49,9 @@ def _affine_args(affine, outer: int):
 class HipReductions:
     name = "hip"
 
-    def pair_stats(self, pred, target, groups: int, rows: int, channels: int, rse_eps: float = 1e-8, affine=None):
-        """affine = (scale, shift), each [groups, channels]: pred is read as pred * scale + shift."""
+    def pair_stats(self, pred, target, groups: int, rows: int, channels: int, rse_eps=None, affine=None):
+        """affine = (scale, shift), each [groups, channels]: pred is read as pred * scale + shift.  rse_eps=None leaves the
+        S_RSE statistic out (zeros); only compute_mean_rse needs it."""
         l = _lib.lib()
         pred, target = _f32c(pred, "pred"), _f32c(target, "target")
         if pred.numel() != groups * rows * channels or target.numel() != pred.numel():
@@ -61,7 +62,7 @@ class HipReductions:
         sc, sh, _ = _affine_args(affine, groups)
         if affine is not None and tuple(affine[0].shape) != (groups, channels):
             raise ValueError(f"pair_stats: the affine map must be [{groups}, {channels}], got {tuple(affine[0].shape)}")
-        _lib.check(l.pde_amd_pair_stats_affine(pred.data_ptr(), target.data_ptr(), groups, rows, channels, float(rse_eps), sc, sh,
+        _lib.check(l.pde_amd_pair_stats_affine(pred.data_ptr(), target.data_ptr(), groups, rows, channels, -1.0 if rse_eps is None else float(rse_eps), sc, sh,
                                                stats.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "pair_stats")
         return stats
 

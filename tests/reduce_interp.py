@@ -37,7 +37,7 @@ class InterpReductions:
             out[:, i] = (np.abs(F[:, members]) ** 2).sum(axis=1)
         return torch.from_numpy(out.astype(np.float32)).to(spectrum.device)
 
-    def pair_stats(self, pred, target, groups, rows, channels, rse_eps=1e-8, affine=None):
+    def pair_stats(self, pred, target, groups, rows, channels, rse_eps=None, affine=None):
         if affine is not None:      # fp32 mul, then add, as torch does
             pred = pred.detach().float().reshape(groups, rows, channels) * affine[0][:, None, :] + affine[1][:, None, :]
         p = _np(pred).reshape(groups, rows, channels)
@@ -48,7 +48,8 @@ class InterpReductions:
         st[..., R.S_G2] = (g * g).sum(1)
         st[..., R.S_G] = g.sum(1)
         st[..., R.S_P] = p.sum(1)
-        st[..., R.S_RSE] = (d * d / (g * g + rse_eps)).sum(1)
+        if rse_eps is not None:
+            st[..., R.S_RSE] = (d * d / (g * g + rse_eps)).sum(1)
         st[..., R.S_MAXD] = np.abs(d).max(1) if rows else 0.0
         return torch.tensor(st, dtype=torch.float64, device=pred.device)
 
