@@ -90,6 +90,30 @@ def _case_accumulator(rank, world):
     return got, want
 
 
+def _case_scale_accumulator(rank, world):
+    """each rank adds its shard of the trajectories; every rank gets the scales of the whole set"""
+    import pde_amd
+    from pde_amd import functional as PF
+    from pde_amd.scales import ResidualScaleAccumulator
+    from tests.spec_interp import InterpBackend
+    PF.set_backend(InterpBackend())
+    g = torch.Generator().manual_seed(2)
+    B = 4
+    fields = [torch.randn(B, 6, 8, 8, generator=g) for _ in range(3)]
+    nu = torch.tensor([0.01, 0.02, 0.05, 0.1])
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01)
+    a, b = pdist.shard_batch(B, rank, world)
+    acc = ResidualScaleAccumulator(fn)
+    acc.update(*[f[a:b].contiguous() for f in fields], nu=nu[a:b])
+    got = acc.result()
+    dist.barrier()
+    # the same on the whole batch, without the collective
+    res = fn.residuals(*fields, nu=nu)
+    sites = res.pop("__sites_per_frame__")
+    want = {eq: torch.sqrt(r.double().square().sum(dim=(0, 2, 3)) / sites).float() for eq, r in res.items()}
+    return ({k: v.tolist() for k, v in got["eq_scales_per_t"].items()}, {k: v.tolist() for k, v in want.items()}, got["eq_scales"])
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _port():
     _free_port.port = _free_port()
@@ -135,3 +159,17 @@ def test_metric_accumulator_world2():
         for c in want["per_timestep_nrmse"]:
             for a, b in zip(got["per_timestep_nrmse"][c], want["per_timestep_nrmse"][c]):
                 assert abs(a - b) <= 1e-6 * b
+
+
+def test_scale_accumulator_world2():
+    _free_port.port = _free_port()
+    ret = _run(_case_scale_accumulator)
+    for r in (0, 1):
+        got, want, scalars = ret[r]
+        assert list(got) == ["continuity", "x_momentum", "y_momentum"]
+        for eq in want:
+            assert len(got[eq]) == 4
+            for x, y in zip(got[eq], want[eq]):
+                assert abs(x - y) <= 1e-6 * abs(y)
+            assert abs(scalars[eq] - (sum(v * v for v in want[eq]) / 4) ** 0.5) <= 1e-5 * scalars[eq]
+    assert ret[0][0] == ret[1][0]
