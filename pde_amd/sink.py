@@ -58,6 +58,8 @@ class _Shared(torch.autograd.Function):
 def shared_grad(output: torch.Tensor) -> torch.Tensor:
     """Tag `output` (fp32, contiguous; other tensors are returned unchanged and untagged) so that the losses of this package
     accumulate their gradients w.r.t. it in one buffer."""
+    if isinstance(output, Denormalised):      # already carries a shared buffer (or was built with share=False on purpose)
+        return output
     if not (output.requires_grad and torch.is_grad_enabled()) or output.dtype != torch.float32 or not output.is_contiguous():
         return output
     sink = GradSink()

@@ -351,6 +351,7 @@ def check_denormalised(dev):
         assert False, "per-frame std must raise"
     except ValueError:
         pass
+    assert pde_amd.shared_grad(den) is den
     try:
         den + 1
         assert False, "a Denormalised is not a tensor"
