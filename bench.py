@@ -146,35 +146,42 @@ def main():
         total.backward(gradient=one)      # the upstream gradient of the loss: a resident 1.0 instead of a fill launch per step
         # detached: nothing of the autograd graph (and its per-leaf accumulation nodes, which remember the stream they
         # were created on) outlives the step, so a later capture on another stream starts clean
-        return total.detach(), {k: v.detach() for k, v in losses.items()}
+        # the step's scalars as one vector, ready for the packed all-reduce
+        return pdist.pack_scalars({"total": total, **losses}), ["total", *losses]
 
     for _ in range(args.warmup):
-        total, losses = loss_step()
-        pdist.reduce_scalars({"total": total, **losses})
+        buf, keys = loss_step()
+        pdist.reduce_packed_async(keys, buf, force=distributed).result()
 
     # The step is launch-bound on the host (five small launches plus autograd for ~0.18 ms of GPU work), so the
     # steady-state loop replays it as a HIP graph; every `probe`-th step of the timed region runs eagerly instead with
     # HIP events recorded right around the forward and the adjoint launches, which is where the roofline numbers
     # come from.  --no-graph runs every step eagerly.
-    graph, g_total, g_losses = None, None, None
+    # Two graphs of the same step that leave their packed scalars in two different buffers: the all-reduce of step i runs in
+    # place on its buffer, beside step i + 1, and is joined before step i + 2 writes that buffer again.
+    graphs, g_bufs = [], []
     if not args.no_graph:
         try:
-            total = losses = None
+            buf = None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 loss_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to query events
-                g_total, g_losses = loss_step()
-            graph.replay()
-            torch.cuda.synchronize()
+            for _ in range(2):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to query events
+                    gb, keys = loss_step()
+                gr.replay()
+                torch.cuda.synchronize()
+                graphs.append(gr)
+                g_bufs.append(gb)
         except Exception as e:      # capture unsupported here: eager loop
             print(f"bench: HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
+            graphs, g_bufs = [], []
             torch.cuda.synchronize()
+    graph = graphs[0] if graphs else None
     probe = 5 if graph is not None else 1
     n_probe = (args.steps + probe - 1) // probe
     pool = lambda: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe + 2)]
@@ -182,14 +189,15 @@ def main():
 
     def step(i):
         if graph is not None and i % probe != probe - 1:
-            graph.replay()
-            total, losses = g_total, g_losses
+            graphs[i % 2].replay()
+            buf = g_bufs[i % 2]
         else:
             backend.backward_events, backend.forward_events = bwd_events, fwd_events
-            total, losses = loss_step()
+            buf, names = loss_step()
             backend.backward_events = backend.forward_events = None
+            return pdist.reduce_packed_async(names, buf, force=distributed)
         # the step's scalars: one packed all-reduce, started now and joined a step later so that it runs beside the next step
-        return pdist.reduce_scalars_async({"total": total, **losses})
+        return pdist.reduce_packed_async(keys, buf, force=distributed)
 
     backend.backward_event_pool, backend.forward_event_pool = pool(), pool()
     if distributed:
@@ -200,7 +208,7 @@ def main():
     for i in range(args.steps):
         nxt = step(i)
         if pending is not None:
-            red = pending.result()
+            pending.join()
         pending = nxt
     red = pending.result()
     if distributed:

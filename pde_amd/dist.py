@@ -27,29 +27,52 @@ class PendingScalars:
     def __init__(self, keys, buf, work, scale, values=None):
         self._keys, self._buf, self._work, self._scale, self._values = keys, buf, work, scale, values
 
-    def result(self) -> Dict[str, torch.Tensor]:
-        if self._values is not None:      # single process: nothing was packed
-            return self._values
+    def join(self) -> None:
+        """Make the current stream wait for the collective; no other device work (the mean's division is left to result())."""
         if self._work is not None:
             self._work.wait()
             self._work = None
-            if self._scale != 1.0:
-                self._buf = self._buf * self._scale
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        if self._values is not None:      # single process: nothing was packed
+            return self._values
+        self.join()
+        if self._scale != 1.0:
+            self._buf, self._scale = self._buf * self._scale, 1.0
         return {k: self._buf[i] for i, k in enumerate(self._keys)}
 
 
-def reduce_scalars_async(values: Dict[str, torch.Tensor], op: str = "mean", group=None) -> PendingScalars:
+def reduce_scalars_async(values: Dict[str, torch.Tensor], op: str = "mean", group=None, force: bool = False) -> PendingScalars:
     """Start ONE all-reduce over a dict of 0-dim tensors and return at once; the collective runs beside whatever is enqueued
     next (the following step), and `.result()` joins it.  With more than one rank the values are copied into the packed buffer first, so the
-    caller may overwrite them; a single process gets its own values back, unpacked and uncopied."""
+    caller may overwrite them; a single process gets its own values back, unpacked and uncopied (force=True runs the collective
+    even then: a rehearsal of the multi-rank path on one device)."""
     if op not in ("mean", "sum"):
         raise ValueError("op must be 'mean' or 'sum'")
     keys = list(values)
     if not keys:
         return PendingScalars(keys, torch.empty(0, dtype=torch.float64), None, 1.0)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return PendingScalars(keys, None, None, 1.0, {k: v.detach() for k, v in values.items()})
     buf = torch.stack([values[k].detach().reshape(()) for k in keys]).to(torch.float64)     # two small kernels, whatever the count
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return PendingScalars(keys, buf, work, 1.0 / dist.get_world_size(group) if op == "mean" else 1.0)
+
+
+def pack_scalars(values: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """The dict's 0-dim tensors as one fp64 vector, in key order (two small kernels, capturable in a HIP graph)."""
+    return torch.stack([v.detach().reshape(()) for v in values.values()]).to(torch.float64)
+
+
+def reduce_packed_async(keys, buf: torch.Tensor, op: str = "mean", group=None, force: bool = False) -> PendingScalars:
+    """reduce_scalars_async for a vector made by pack_scalars: the all-reduce runs IN PLACE on `buf`, which the caller
+    must leave alone until join() / result().  Nothing else is launched on the current stream, so a step that produces
+    `buf` inside a replayed graph pays no eager kernels for its logging."""
+    if op not in ("mean", "sum"):
+        raise ValueError("op must be 'mean' or 'sum'")
+    keys = list(keys)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return PendingScalars(keys, buf, None, 1.0)
     work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return PendingScalars(keys, buf, work, 1.0 / dist.get_world_size(group) if op == "mean" else 1.0)
 

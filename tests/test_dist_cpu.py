@@ -50,6 +50,12 @@ def _case_reduce(rank, world):
     vals["total"].fill_(-1.0)
     late = pend.result()
     assert {k: float(v) for k, v in late.items()} == {k: float(v) for k, v in mean.items()}
+    # the packed form: in place on the caller's vector, joined without further device work, scaled on result()
+    buf = pdist.pack_scalars({"total": torch.tensor(1.0 + rank), "continuity": torch.tensor(10.0 * (rank + 1))})
+    pk = pdist.reduce_packed_async(["total", "continuity"], buf)
+    pk.join()
+    assert buf.tolist() == [3.0, 30.0]                      # the sum, in place
+    assert {k: float(v) for k, v in pk.result().items()} == {k: float(v) for k, v in mean.items()}
     return {k: float(v) for k, v in mean.items()}, {k: float(v) for k, v in tot.items()}
 
 
