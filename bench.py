@@ -154,7 +154,7 @@ def main():
         pdist.reduce_packed_async(keys, buf, force=distributed).result()
 
     # The step is launch-bound on the host (five small launches plus autograd for ~0.18 ms of GPU work), so the
-    # steady-state loop replays it as a HIP graph; every `probe`-th step of the timed region runs eagerly instead with
+    # steady-state loop replays it as a HIP graph; every `probe`-th step (10th by default) of the timed region runs eagerly instead with
     # HIP events recorded right around the forward and the adjoint launches, which is where the roofline numbers
     # come from.  --no-graph runs every step eagerly.
     # Two graphs of the same step that leave their packed scalars in two different buffers: the all-reduce of step i runs in
@@ -182,7 +182,8 @@ def main():
             graphs, g_bufs = [], []
             torch.cuda.synchronize()
     graph = graphs[0] if graphs else None
-    probe = 5 if graph is not None else 1
+    # an eager probe step costs about twice a replayed one (the host cannot keep up), so only every 10th step is one
+    probe = max(2, min(10, args.steps // 3)) if graph is not None else 1
     n_probe = (args.steps + probe - 1) // probe
     pool = lambda: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe + 2)]
     bwd_events, fwd_events = [], []
@@ -238,7 +239,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank,
-                       "launch": "hip-graph replay, every 5th step eager with kernel events" if graph is not None else "eager",
+                       "launch": f"hip-graph replay, every {probe}th step eager with kernel events" if graph is not None else "eager",
                        "backward_mode": args.mode},
             "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step; HIP events recorded by "
                                                      "the library on the launch stream right before and after that launch" +
