@@ -336,6 +336,31 @@ def check_denormalised(dev):
             assert float(x.detach()) == float(y.detach()), (share, float(x.detach()), float(y.detach()))
         assert _rel(b.grad.cpu().numpy(), a.grad.cpu().numpy()) <= 2e-6, share
         assert np.array_equal((b.grad == 0).cpu().numpy(), (a.grad == 0).cpu().numpy())
+    # 1-D and 3-D layouts: strips / shells and the single-field gathers, values bit for bit, gradients to fp32 accuracy
+    for shape, pde in (((2, 3, 24, C), "b1d"), ((2, 3, 8, 6, 8, C), "h3d")):
+        nd = len(shape) - 3
+        o0 = torch.randn(*shape, generator=gen).to(dev)
+        i0 = torch.randn(*shape, generator=gen).to(dev)
+        t0 = torch.randn(*shape, generator=gen).to(dev)
+        bc = (shape[0],) + (1,) * (nd + 1) + (C,)
+        mu, sd = (0.3 * torch.randn(*bc, generator=gen)).to(dev), (0.5 + torch.rand(*bc, generator=gen)).to(dev)
+        m3 = torch.zeros(shape[0], C); m3[:, [0, 3, 5]] = 1
+        m3 = m3.to(dev)
+        par = torch.tensor([0.02, 0.05]).to(dev)
+        if pde == "b1d":
+            fn1 = pde_amd.Burgers1DPDELoss(dx=2 * np.pi / 24, dt=0.01).to(dev)
+            f = lambda o: PB.compute_boundary_loss(o, t0, m3, 2) + 1e-6 * PG.compute_pde_loss_burgers_1d(o, i0, fn1, par)[0]
+        else:
+            fn1 = pde_amd.Heat3DPDELoss(nx=8, ny=6, nz=8).to(dev)
+            f = lambda o: PB.compute_boundary_loss(o, t0, m3, 1) + 1e-3 * PG.compute_pde_loss_heat_3d(o, i0, fn1, par)[0]
+        a1 = o0.clone().requires_grad_(True)
+        l1 = f(a1 * sd + mu)
+        l1.backward()
+        b1 = o0.clone().requires_grad_(True)
+        l2 = f(pde_amd.Denormalised(b1, mu, sd))
+        l2.backward()
+        assert float(l1.detach()) == float(l2.detach()), pde
+        assert _rel(b1.grad.cpu().numpy(), a1.grad.cpu().numpy()) <= 2e-6, pde
     # compute_vrmse applies std and mean while reading (per-sample groups, so only the order of the fp64 sums differs);
     # consumers outside the package take the materialised product
     den = pde_amd.Denormalised(on0, mean, std)
