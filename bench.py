@@ -1,16 +1,19 @@
 """Benchmark: fused PDE-residual loss forward+backward, Taylor-Green 2-D, B=16 T=16 256x256 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rotate K]
 
 One step = one TaylorGreen2DPDELoss forward + backward over one batch of synthetic fields already
-resident in HBM.  With N > 1 (launched through torch.distributed.run, one rank per GPU) every rank owns
-its own 16 samples (weak scaling) and the step's loss scalars go through one packed RCCL all-reduce.
-Rank 0 prints one JSON line.
+resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 16 samples (weak scaling)
+and the step's loss scalars go through one packed RCCL all-reduce.  `python bench.py --gpus N` starts
+the N ranks itself (a torch.distributed.run child process, started before anything touches the GPU);
+under an external launcher (WORLD_SIZE set) it is one of the ranks.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,48 +50,49 @@ def synth_fields(b, t, h, w, seed, device):
     return out
 
 
-def cpu_baseline(seconds=12.0):
-    """The CPU oracle (reference-equivalent eager PyTorch, fp32) on a bounded sample of the same workload."""
+def _time_oracle(bs, seconds, min_passes, threads=None):
+    """Best fwd+bwd time of the CPU oracle on a batch of `bs` samples of the benchmark's shape."""
     from oracle import classes as OC
-    bs = 2
     g = torch.Generator().manual_seed(1234)
     fields = [torch.randn(bs, T, H, W, generator=g).requires_grad_(True) for _ in range(3)]
     nu = 0.01 + 0.09 * torch.rand(bs, generator=g)
     fn = OC.build("TaylorGreen2DPDELoss", nx=W, ny=H, dt=0.01, eq_scales=EQ_SCALES)
-    pts = bs * (T - 2) * H * W
-    n, t0 = 0, None
-    best = float("inf")
-    start = time.perf_counter()
-    while True:
-        for f in fields:
-            f.grad = None
-        t0 = time.perf_counter()
-        total, _ = fn(*fields, nu=nu)
-        total.backward()
-        dt = time.perf_counter() - t0
-        n += 1
-        if n > 1:
-            best = min(best, dt)
-        if time.perf_counter() - start > seconds and n >= 3:
-            break
-    # the same sample on one thread (a few passes only)
-    threads = torch.get_num_threads()
-    one = float("inf")
+    old = torch.get_num_threads()
+    if threads is not None:
+        torch.set_num_threads(threads)
     try:
-        torch.set_num_threads(1)
-        for i in range(3):
+        n, best = 0, float("inf")
+        start = time.perf_counter()
+        while True:
             for f in fields:
                 f.grad = None
             t0 = time.perf_counter()
             total, _ = fn(*fields, nu=nu)
             total.backward()
-            if i:
-                one = min(one, time.perf_counter() - t0)
+            dt = time.perf_counter() - t0
+            n += 1
+            if n > 1:                      # the first pass warms the allocator up
+                best = min(best, dt)
+            if n >= min_passes + 1 and time.perf_counter() - start > seconds:
+                break
     finally:
-        torch.set_num_threads(threads)
-    return {"value": pts / best, "unit": "grid-points/s", "cores": threads, "kind": "port",
-            "sample": f"oracle TaylorGreen2D fwd+bwd fp32, B={bs} T={T} {H}x{W}, best of {n - 1} after warm-up",
-            "one_thread_value": pts / one}
+        torch.set_num_threads(old)
+    return bs * (T - 2) * H * W / best, n - 1
+
+
+def cpu_baseline():
+    """The CPU oracle (reference-equivalent eager PyTorch, fp32) on the benchmark's own batch (B=16), all host threads
+    torch uses; next to it a B=2 sample, which stays cache-resident and runs far faster per point, and the same on
+    one thread."""
+    threads = torch.get_num_threads()
+    full, n_full = _time_oracle(B, 14.0, 2)
+    small, _ = _time_oracle(2, 4.0, 3)
+    one, _ = _time_oracle(2, 0.0, 2, threads=1)
+    return {"value": full, "unit": "grid-points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle TaylorGreen2D fwd+bwd fp32 at the benchmark's batch, B={B} T={T} {H}x{W}, best of {n_full} "
+                      f"passes after one warm-up",
+            "small_sample_value": small, "small_sample": f"B=2 T={T} {H}x{W} (cache-resident)",
+            "one_thread_value": one}
 
 
 def measured_traffic(kernel_substr):
@@ -106,31 +110,100 @@ def measured_traffic(kernel_substr):
     return None
 
 
-def main():
+def launch_command(gpus, argv, port, python=None):
+    """The child command that starts `gpus` ranks of this script on one node (one process per GPU)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="number of independent input sets the steps cycle through; 4 sets (805 MB of fields, as much again of "
+                         "gradients) exceed the 256 MiB Infinity Cache, so every step reads its fields from HBM ('cold'); "
+                         "1 = the same 201 MB every step ('warm')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--mode", default="fused", choices=["fused", "auto"],
                     help="loss module backward_mode: 'fused' = loss and gradient in one pass of the adjoint kernel (it recomputes "
                          "every residual anyway), 'auto' = forward kernel, then adjoint kernel")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--dry", action="store_true",
+                    help="rehearse the launcher, the rendezvous and the packed all-reduce without a GPU: no kernel runs, "
+                         "the printed value is 0 and the line carries \"dry\": true (use with --backend gloo)")
+    return ap.parse_args(argv)
+
+
+def dry_run(args, world, rank):
+    """The bench's distributed skeleton on CPU tensors: rendezvous, warm-up, timed loop of packed all-reduces, one JSON line."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(args.backend)
+    keys = ["total", "continuity", "x_momentum", "y_momentum"]
+    red = None
+    for i in range(args.warmup + args.steps):
+        buf = torch.tensor([1.0 + rank, 2.0, 3.0, 4.0], dtype=torch.float64)
+        red = pdist.reduce_packed_async(keys, buf).result()
+    if world > 1:
+        dist.barrier()
+        n = torch.ones(1)
+        dist.all_reduce(n)
+        assert int(n) == world
+    if rank == 0:
+        print(json.dumps({"metric": "PDE-residual loss fwd+bwd grid-points/sec", "value": 0.0, "unit": "grid-points/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry": True,
+                          "config": {"parallelism": f"dp{world}"}, "loss": float(red["total"])}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Not under a launcher: start the ranks as a child process group.  Nothing in this process has touched the GPU yet
+        # (importing torch and pde_amd does not), and it never will: it only relays the child's exit status; rank 0 of
+        # the child prints the JSON line on the shared stdout.
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1" if args.dry else os.environ.get("OMP_NUM_THREADS", "4"))
+        return subprocess.run(launch_command(args.gpus, argv, free_port()), env=env).returncode
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus must be the world size", file=sys.stderr)
+        return 2
+    if args.dry:
+        dry_run(args, world, rank)
+        return 0
     distributed = world > 1 or os.environ.get("PDE_AMD_BENCH_FORCE_DIST") == "1"     # the latter: rehearse the RCCL path with one rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, device_id=dev)
+        assert dist.get_world_size() == world
 
-    fields = [f.requires_grad_(True) for f in synth_fields(B, T, H, W, 1234 + 1000 * 2 + rank, dev)]
-    gnu = torch.Generator(device=dev).manual_seed(99 + rank)
-    nu = 0.01 + 0.09 * torch.rand(B, generator=gnu, device=dev)
+    n_sets = max(1, args.rotate)
+    sets = []
+    for k in range(n_sets):
+        fs = [f.requires_grad_(True) for f in synth_fields(B, T, H, W, 1234 + 1000 * 2 + 17 * k + rank, dev)]
+        gnu = torch.Generator(device=dev).manual_seed(99 + 31 * k + rank)
+        sets.append((fs, 0.01 + 0.09 * torch.rand(B, generator=gnu, device=dev)))
     loss_fn = pde_amd.TaylorGreen2DPDELoss(nx=W, ny=H, dt=0.01, eq_scales=EQ_SCALES).to(dev)
     loss_fn.backward_mode = args.mode      # upstream_hint stays 1.0: the step backpropagates `total` itself
 
@@ -138,41 +211,40 @@ def main():
 
     one = torch.ones((), device=dev)
 
-    def loss_step():
-        """forward + backward of the loss through the nn.Module API; gradients land in fields[i].grad"""
+    def loss_step(k):
+        """forward + backward of the loss on input set k through the nn.Module API; gradients land in fields[i].grad"""
+        fields, nu = sets[k]
         for f in fields:
             f.grad = None
         total, losses = loss_fn(*fields, nu=nu)
         total.backward(gradient=one)      # the upstream gradient of the loss: a resident 1.0 instead of a fill launch per step
-        # detached: nothing of the autograd graph (and its per-leaf accumulation nodes, which remember the stream they
-        # were created on) outlives the step, so a later capture on another stream starts clean
-        # the step's scalars as one vector, ready for the packed all-reduce
+        # the step's scalars as one vector, ready for the packed all-reduce (detached: nothing of the autograd graph
+        # outlives the step, so a later capture on another stream starts clean)
         return pdist.pack_scalars({"total": total, **losses}), ["total", *losses]
 
-    for _ in range(args.warmup):
-        buf, keys = loss_step()
+    for i in range(max(args.warmup, n_sets)):
+        buf, keys = loss_step(i % n_sets)
         pdist.reduce_packed_async(keys, buf, force=distributed).result()
 
-    # The step is launch-bound on the host (five small launches plus autograd for ~0.18 ms of GPU work), so the
-    # steady-state loop replays it as a HIP graph; every `probe`-th step (10th by default) of the timed region runs eagerly instead with
-    # HIP events recorded right around the forward and the adjoint launches, which is where the roofline numbers
-    # come from.  --no-graph runs every step eagerly.
-    # Two graphs of the same step that leave their packed scalars in two different buffers: the all-reduce of step i runs in
-    # place on its buffer, beside step i + 1, and is joined before step i + 2 writes that buffer again.
+    # The step is launch-bound on the host (a few small launches plus autograd for ~0.15 ms of GPU work), so the
+    # steady-state loop replays it as a HIP graph; every `probe`-th step of the timed region runs eagerly instead with
+    # HIP events recorded right around the adjoint launch, which is where the roofline numbers come from.
+    # --no-graph runs every step eagerly.  One graph per input set (two for a single set), each leaving its packed
+    # scalars in its own buffer: the all-reduce of step i runs in place on its buffer, beside step i + 1, and is joined
+    # before that buffer is written again.
     graphs, g_bufs = [], []
     if not args.no_graph:
         try:
-            buf = None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                loss_step()
+                loss_step(0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            for _ in range(2):
+            for j in range(max(2, n_sets)):
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to query events
-                    gb, keys = loss_step()
+                    gb, keys = loss_step(j % n_sets)
                 gr.replay()
                 torch.cuda.synchronize()
                 graphs.append(gr)
@@ -182,25 +254,26 @@ def main():
             graphs, g_bufs = [], []
             torch.cuda.synchronize()
     graph = graphs[0] if graphs else None
-    # an eager probe step costs about twice a replayed one (the host cannot keep up), so only every 10th step is one
+    # an eager probe step costs more than a replayed one (the host cannot keep up), so only every 10th step is one
     probe = max(2, min(10, args.steps // 3)) if graph is not None else 1
+    if graph is not None and n_sets > 1 and probe % n_sets == 0:
+        probe += 1                       # the probes visit every input set in turn
     n_probe = (args.steps + probe - 1) // probe
-    pool = lambda: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe + 2)]
+    pool = lambda n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n + 2)]
     bwd_events, fwd_events = [], []
 
     def step(i):
         if graph is not None and i % probe != probe - 1:
-            graphs[i % 2].replay()
-            buf = g_bufs[i % 2]
-        else:
-            backend.backward_events, backend.forward_events = bwd_events, fwd_events
-            buf, names = loss_step()
-            backend.backward_events = backend.forward_events = None
-            return pdist.reduce_packed_async(names, buf, force=distributed)
+            j = i % len(graphs)
+            graphs[j].replay()
+            return pdist.reduce_packed_async(keys, g_bufs[j], force=distributed)
+        backend.backward_events, backend.forward_events = bwd_events, fwd_events
+        buf, names = loss_step(i % n_sets)
+        backend.backward_events = backend.forward_events = None
         # the step's scalars: one packed all-reduce, started now and joined a step later so that it runs beside the next step
-        return pdist.reduce_packed_async(keys, buf, force=distributed)
+        return pdist.reduce_packed_async(names, buf, force=distributed)
 
-    backend.backward_event_pool, backend.forward_event_pool = pool(), pool()
+    backend.backward_event_pool, backend.forward_event_pool = pool(n_probe + 40), pool(n_probe + 40)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -232,6 +305,22 @@ def main():
         e_in = 3 * B * T * H * W
         bwd_bytes = 8 * e_in            # adjoint: read every field once, write every gradient once
         achieved = bwd_bytes / (bwd_avg * 1e-3) / 1e9
+        # after the timed region: the same kernel on ONE input set, step after step, so that its 201 MB of fields stay in
+        # the Infinity Cache between launches (the gradient stores are nontemporal and do not displace them)
+        other = {}
+        if n_sets > 1:
+            warm = []
+            backend.backward_events, backend.forward_events = warm, []
+            for _ in range(24):
+                loss_step(0)
+            backend.backward_events = backend.forward_events = None
+            torch.cuda.synchronize()
+            w_ms = sorted(x.elapsed_time(y) for x, y in warm)[: 16]      # the first launches still find another set cached
+            w_avg = sum(w_ms) / len(w_ms)
+            other = {"warm_avg_ms": w_avg, "warm_achieved": bwd_bytes / (w_avg * 1e-3) / 1e9,
+                     "warm_frac": bwd_bytes / (w_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        cache = (f"cold: the steps cycle through {n_sets} input sets ({n_sets * 4 * e_in / 1e6:.0f} MB of fields), more than the 256 MiB "
+                 f"Infinity Cache holds; warm_*: one set, step after step") if n_sets > 1 else "warm: the same input set every step"
         out = {
             "metric": "PDE-residual loss fwd+bwd grid-points/sec",
             "value": value, "unit": "grid-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,13 +329,13 @@ def main():
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank,
                        "launch": f"hip-graph replay, every {probe}th step eager with kernel events" if graph is not None else "eager",
-                       "backward_mode": args.mode},
+                       "backward_mode": args.mode, "input_sets": n_sets},
             "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step; HIP events recorded by "
                                                      "the library on the launch stream right before and after that launch" +
                                                      ("; in fused mode the kernel also sums the loss)" if args.mode == "fused" else ")"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("bwd_march_q_kernel<pde_amd::Pde_tg2d, 4, true>" if args.mode == "fused" else "bwd_march_q_kernel<pde_amd::Pde_tg2d, 4>"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
-                         "median_ms": k_ms[len(k_ms) // 2], "timed_launches": len(k_ms),
+                         "median_ms": k_ms[len(k_ms) // 2], "timed_launches": len(k_ms), "cache": cache, **other,
                          **({"fwd_median_ms": f_ms[len(f_ms) // 2], "fwd_algorithmic_bytes": 4 * e_in,
                              "fwd_traffic": measured_traffic("fwd_march_q_kernel")} if f_ms else {})},
             "loss": float(red["total"]),
@@ -256,7 +345,8 @@ def main():
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
