@@ -27,7 +27,8 @@ typedef enum pde_amd_status {
   PDE_AMD_EINVAL = -1,      /* null pointer / unknown pde id / bad count */
   PDE_AMD_ESHAPE = -2,      /* extents the kernels cannot handle (e.g. periodic axis shorter than a halo) */
   PDE_AMD_EWORKSPACE = -3,  /* workspace too small */
-  PDE_AMD_EHIP = -4         /* a HIP launch failed; hipGetLastError has the cause */
+  PDE_AMD_EHIP = -4,        /* a HIP call failed; hipGetLastError has the cause */
+  PDE_AMD_ESCRATCH = -5     /* pde_amd_residual_forward_backward_static: the problem needs more than the static scratch */
 } pde_amd_status;
 
 /* One residual-loss problem: which PDE, the field extents [B, T, n0, n1, n2] (unused leading spatial
@@ -102,6 +103,22 @@ int pde_amd_residual_forward_backward(const pde_amd_problem* prob,
                                       const float* const* sparams, const float* weights,
                                       const float* upstream_total, double* sums, float* totals,
                                       float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* pde_amd_residual_forward_backward for callers that cannot allocate device memory or hand over a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments, results and kernels, but the partial sums live in a device array inside the library of
+ * PDE_AMD_STATIC_SCRATCH_BYTES bytes, which every GPU the library runs on holds until the process ends; the call makes
+ * no allocation of any kind.  Problems with pde_amd_residual_workspace_bytes(prob) above that size are rejected with
+ * PDE_AMD_ESCRATCH (every configuration of the reference's trainers fits: the largest, shear flow at B = 64, needs
+ * 3.5 MiB).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * calls on one stream, or otherwise ordered, do not.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress), so make it outside stream capture. */
+#define PDE_AMD_STATIC_SCRATCH_BYTES 4194304
+int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob,
+                                             const float* const* fields, const float* const* aux,
+                                             const float* const* sparams, const float* weights,
+                                             const float* upstream_total, double* sums, float* totals,
+                                             float* const* grads, void* stream);
 
 /* Measurement hook, no counterpart in the reference: the next launch of the register-blocked adjoint kernel issued from
  * this host thread (by pde_amd_residual_backward in recompute mode or by pde_amd_residual_forward_backward) records the

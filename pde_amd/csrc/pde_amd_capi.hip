@@ -4,6 +4,11 @@
 #include "stencil_quad.hpp"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
+
+// Partial-sum scratch of pde_amd_residual_forward_backward_static: one copy per GPU, held until the process ends.
+// In host code this name is only a handle for hipGetSymbolAddress; the kernels get the per-device address it returns.
+static __device__ __align__(256) unsigned char scratch[PDE_AMD_STATIC_SCRATCH_BYTES];
 
 namespace pde_amd {
 #include "gen/registry.inc"
@@ -411,6 +416,7 @@ const char* pde_amd_status_string(int status) {
     case PDE_AMD_ESHAPE: return "unsupported shape";
     case PDE_AMD_EWORKSPACE: return "workspace too small";
     case PDE_AMD_EHIP: return "HIP launch failed";
+    case PDE_AMD_ESCRATCH: return "problem needs more partial-sum scratch than PDE_AMD_STATIC_SCRATCH_BYTES";
     default: return "unknown status";
   }
 }
@@ -447,6 +453,39 @@ int pde_amd_residual_forward_backward(const pde_amd_problem* prob, const float* 
   if (!v) return PDE_AMD_EINVAL;
   return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+// The device address of `scratch` on the current GPU, looked up once per device (each GPU holds its own copy).
+static int static_scratch(void** out) {
+  constexpr int kMaxDevices = 64;
+  static void* ptrs[kMaxDevices] = {};
+  static std::mutex mu;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return PDE_AMD_EHIP;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptrs[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PDE_AMD_EHIP;
+    ptrs[dev] = p;
+  }
+  *out = ptrs[dev];
+  return PDE_AMD_OK;
+}
+
+int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob, const float* const* fields,
+                                             const float* const* aux, const float* const* sparams, const float* weights,
+                                             const float* upstream_total, double* sums, float* totals,
+                                             float* const* grads, void* stream) {
+  const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
+  if (!v) return PDE_AMD_EINVAL;
+  const size_t need = v->ws_bytes(prob);
+  if (need > PDE_AMD_STATIC_SCRATCH_BYTES) return PDE_AMD_ESCRATCH;
+  void* ws = nullptr;
+  const int st = static_scratch(&ws);
+  if (st) return st;
+  // every partial sum the reduction reads is written by the kernel before it, so nothing has to be cleared between calls
+  return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, ws,
+                    PDE_AMD_STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream));
 }
 
 int pde_amd_time_next_adjoint(void* start_event, void* stop_event) {
