@@ -18,7 +18,7 @@ extern "C" {
 
 #define PDE_AMD_MAX_FIELDS 4
 #define PDE_AMD_MAX_EQS 4
-#define PDE_AMD_MAX_AUX 1
+#define PDE_AMD_MAX_AUX 2
 #define PDE_AMD_MAX_SPARAMS 3
 #define PDE_AMD_MAX_CONSTS 16
 
@@ -28,7 +28,9 @@ typedef enum pde_amd_status {
   PDE_AMD_ESHAPE = -2,      /* extents the kernels cannot handle (e.g. periodic axis shorter than a halo) */
   PDE_AMD_EWORKSPACE = -3,  /* workspace too small */
   PDE_AMD_EHIP = -4,        /* a HIP call failed; hipGetLastError has the cause */
-  PDE_AMD_ESCRATCH = -5     /* pde_amd_residual_forward_backward_static: the problem needs more than the static scratch */
+  PDE_AMD_ESCRATCH = -5,    /* pde_amd_residual_forward_backward_static: the problem needs more than the static scratch */
+  PDE_AMD_EEVENT = -6       /* an event armed with pde_amd_time_next_adjoint could not be recorded (e.g. under stream capture);
+                               the kernels of the call were launched all the same */
 } pde_amd_status;
 
 /* One residual-loss problem: which PDE, the field extents [B, T, n0, n1, n2] (unused leading spatial

@@ -42,11 +42,12 @@ class _Cls:
     scale_key = {}
     total_key = False
     defaults: Dict[str, object] = {}
+    default_scales: Dict[str, float] = {}
 
     def __init__(self, **kw):
         self.kw = {**self.defaults, **kw}
         keys = [self.scale_key.get(e, e) for e in self.eqs]
-        self.scales = {**{k: 1.0 for k in keys}, **(self.kw.get("eq_scales") or {})}
+        self.scales = {**{k: 1.0 for k in keys}, **self.default_scales, **(self.kw.get("eq_scales") or {})}
         self.weights = {**{k: 1.0 for k in keys}, **(self.kw.get("eq_weights") or {})}
         self.per_t_bufs = {k: torch.as_tensor(v).float() for k, v in (self.kw.get("eq_scales_per_t") or {}).items()} \
             if self.kw.get("eq_scales_per_t") is not None else None
@@ -212,6 +213,30 @@ _mk("Heat3DPDELoss", ("heat",), dict(nx=128, ny=128, nz=128, Lx=TWO_PI, Ly=TWO_P
     lambda s, u, alpha=None: s.finish(O.residuals_heat3d(u, s.kw["alpha"] if alpha is None else alpha, dx=s.kw["Lx"] / s.kw["nx"],
                                                          dy=s.kw["Ly"] / s.kw["ny"], dz=s.kw["Lz"] / s.kw["nz"], dt=s.kw["dt"])),
     per_t="slice", total_key=True)
+
+
+def _tg3(s, u, v, w, p, nu=None):
+    k = s.kw
+    nu = k["nu"] if nu is None else nu
+    return s.finish(O.residuals_tg3d(u, v, w, p, nu, dx=k["Lx"] / k["nx"], dy=k["Ly"] / k["ny"], dz=k["Lz"] / k["nz"], dt=k["dt"]))
+
+
+# no class of these names exists in the reference tree; arithmetic from its verification code (see pde_oracle.py)
+_mk("TaylorGreen3DPDELoss", ("continuity", "u_momentum", "v_momentum", "w_momentum"),
+    dict(nx=64, ny=64, nz=64, Lx=TWO_PI, Ly=TWO_PI, Lz=TWO_PI, dt=0.01, nu=0.01), _tg3)
+_mk("NSIncomPDELoss", ("continuity", "u_momentum", "v_momentum", "tracer"),
+    dict(nx=512, ny=512, Lx=1.0, Ly=1.0, dt=0.005, nu=0.01, skip_bl=2, use_div_correction=True),
+    lambda s, u, v, p, d, fx, fy: s.finish(O.residuals_ns_incom(
+        u, v, p, d, fx, fy, dx=s.kw["Lx"] / s.kw["nx"], dy=s.kw["Ly"] / s.kw["ny"], dt=s.kw["dt"], nu=s.kw["nu"],
+        skip=s.kw["skip_bl"], use_div_correction=s.kw["use_div_correction"])),
+    # defaults quoted at configs/finetune_ns_incom_v3.yaml:119-126
+    default_scales={"continuity": 7e-4, "u_momentum": 1.34, "v_momentum": 1.31, "tracer": 0.24})
+# the 2-D class finetune/train_taylor_green_lora_v3.py:66,341-348 imports: its successor's arithmetic, `nu` as fallback
+_mk("TaylorGreenPDELoss", ("continuity", "x_momentum", "y_momentum"),
+    dict(nx=256, ny=256, Lx=TWO_PI, Ly=TWO_PI, dt=0.001, nu=0.001),
+    lambda s, u, v, p, nu=None: s.finish(O.residuals_tg2d(u, v, p, s.kw["nu"] if nu is None else nu, dx=s.kw["Lx"] / s.kw["nx"],
+                                                          dy=s.kw["Ly"] / s.kw["ny"], dt=s.kw["dt"])),
+    guarded=("x_momentum", "y_momentum"))
 
 
 def build(cls_name: str, **kwargs):

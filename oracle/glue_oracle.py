@@ -65,6 +65,14 @@ def boundary_3d_shells(pred, target, mask, w=1):
     return _rmse_of([(pred[:, :, a, b, c][..., ch], target[:, :, a, b, c][..., ch]) for a, b, c in boxes])
 
 
+def boundary_3d_xy_strips(pred, target, mask, w=1):
+    # finetune/train_burgers_3d_apebench_lora.py:128-150 on [B, T, X, Y, Z, C]: the 2-D strip slicing over X and Y, with the
+    # channel list applied to dim 4 (the Z axis) and every channel kept
+    ch = _valid(mask)
+    boxes = [(slice(None, w), slice(None)), (slice(-w, None), slice(None)), (slice(w, -w), slice(None, w)), (slice(w, -w), slice(-w, None))]
+    return _rmse_of([(pred[:, :, a, b][:, :, :, :, ch], target[:, :, a, b][:, :, :, :, ch]) for a, b in boxes])
+
+
 def noslip(output, ch_vx=0, ch_vy=1):
     # finetune/train_ns_incom_lora_v3.py:159-176
     tot = 0.0

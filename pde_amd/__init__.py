@@ -9,12 +9,13 @@ from .losses import (  # noqa: F401
     APEBenchBurgers2DPDELoss, NSPwCPDELoss, KP2DPDELoss, ShearFlowPDELossNPINN, Burgers2DCHPDELoss,
     ActiveMatterNPINNPDELoss, RayleighBenardFullPDELoss, TurbulentRadiativePDELoss, WaveGaussPDELoss,
     GrayScottPDELoss, Advection3DPDELoss, APEBenchBurgers3DPDELoss, SwiftHohenberg3DPDELoss, Heat3DPDELoss,
+    TaylorGreenPDELoss, TaylorGreen3DPDELoss, NSIncomPDELoss,
     burgers_pde_loss, burgers_pde_loss_upwind,
 )
 
 from .boundary import (  # noqa: F401
     compute_boundary_loss, boundary_loss_1d, boundary_loss_2d_strips, boundary_loss_2d_edges, boundary_loss_3d_faces,
-    boundary_loss_3d_shells, compute_noslip_loss, compute_patch_boundary_loss,
+    boundary_loss_3d_shells, boundary_loss_3d_xy_strips, compute_noslip_loss, compute_patch_boundary_loss, PeriodicBCLoss,
 )
 from .metrics import (  # noqa: F401
     compute_vrmse, nrmse_per_sample, nrmse_per_channel, compute_rse, compute_mean_rse, metric_func, NRMSEAccumulator,

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL: shares libamdhip64 with the exte
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDE_AMD_LIB", os.path.join(_HERE, "libpde_amd.so"))   # override: A/B builds while tuning
 
-MAX_FIELDS, MAX_EQS, MAX_AUX, MAX_SPARAMS, MAX_CONSTS = 4, 4, 1, 3, 16
+MAX_FIELDS, MAX_EQS, MAX_AUX, MAX_SPARAMS, MAX_CONSTS = 4, 4, 2, 3, 16
 
 
 class Problem(C.Structure):

@@ -180,8 +180,9 @@ def boundary_loss_1d(pred, target, channel_mask, bc_width: int = 1) -> torch.Ten
 
 
 def boundary_loss_2d_strips(pred, target, channel_mask, bc_width: int = 1) -> torch.Tensor:
-    """finetune/train_taylor_green_2d_lora_v3.py:132-166 (same in train_rayleigh_benard_lora_v3.py:138-175,
-    train_burgers_3d_apebench_lora.py:115-150) — [B, T, H, W, C]; top/bottom full rows, left/right without corners."""
+    """finetune/train_taylor_green_2d_lora_v3.py:132-166 (same in train_rayleigh_benard_lora_v3.py:138-175) —
+    [B, T, H, W, C]; top/bottom full rows, left/right without corners.  train_burgers_3d_apebench_lora.py:115-150 is the
+    same text applied to a 6-D tensor, which gives different arithmetic: see boundary_loss_3d_xy_strips."""
     ch, w = valid_channels(channel_mask), bc_width
     H, W = pred.shape[2], pred.shape[3]
 
@@ -248,9 +249,69 @@ def boundary_loss_3d_shells(pred, target, channel_mask, bc_width: int = 1) -> to
     return _rmse(pred, target, _cached(("3ds", tuple(pred.shape[2:]), tuple(ch), w), build))
 
 
+def boundary_loss_3d_xy_strips(pred, target, channel_mask, bc_width: int = 1) -> torch.Tensor:
+    """finetune/train_burgers_3d_apebench_lora.py:115-150 as it behaves on that trainer's [B, T, X, Y, Z, C] tensors: the
+    2-D strip slicing runs over X and Y (top/bottom full rows of X, left/right strips of Y without the corners), the
+    channel list indexes dim 4, i.e. selects Z planes, and all C channels are kept.  Reproduced because that trainer's
+    loss values depend on it; Z must exceed the largest valid channel index, as in the reference."""
+    ch, w = valid_channels(channel_mask), bc_width
+    X, Y, Z, Cn = pred.shape[2], pred.shape[3], pred.shape[4], pred.shape[5]
+    if ch and max(ch) >= Z:
+        raise IndexError(f"index {max(ch)} is out of bounds for dimension 4 with size {Z}")
+
+    def build():
+        ts = TermSet(_dims4(pred.shape, 3))
+        ay, ac = list(range(Y)), list(range(Cn))
+        ts.add([_sl(X, slice(None, w)), ay, ch, ac])
+        ts.add([_sl(X, slice(-w, None)), ay, ch, ac])
+        mid = _sl(X, slice(w, -w))
+        ts.add([mid, _sl(Y, slice(None, w)), ch, ac])
+        ts.add([mid, _sl(Y, slice(-w, None)), ch, ac])
+        return ts
+    return _rmse(pred, target, _cached(("3dxy", tuple(pred.shape[2:]), tuple(ch), w), build))
+
+
+class PeriodicBCLoss(torch.nn.Module):
+    """tools/test_gt_periodic_bc.py:38-105 (tools/test_gt_fp32_pde_bc.py:17 imports it from the loss library, which does not
+    define it): for every field [B, T, H, W] or [T, H, W], the mean squared mismatch of the linear extrapolation across the
+    periodic wrap, (2 f[-1] - f[-2] - f[0])^2, along dim -2 ("x") and dim -1 ("y").
+    forward({name: field}) -> (total, {name_val_x, name_val_y, name_total, ..., total})."""
+
+    def __init__(self, dx: float, dy: float):
+        super().__init__()
+        self.dx, self.dy = dx, dy
+
+    def forward(self, fields: Dict[str, torch.Tensor], reduction: str = "mean"):
+        losses: Dict[str, torch.Tensor] = {}
+        total = None
+        taps = lambda n: ((0, -1.0), (1, 2.0), (-(n - 2), -1.0))      # anchored at index n - 2: -f[n-2] + 2 f[n-1] - f[0]
+        for name, f in fields.items():
+            x = f if f.dim() == 4 else f.unsqueeze(0)
+            x = x.unsqueeze(-1)                                        # one channel
+            H, W = x.shape[2], x.shape[3]
+            if H < 2 or W < 2:
+                raise IndexError("PeriodicBCLoss needs at least two points along both axes")
+
+            def build():
+                ts = TermSet(_dims4(x.shape, 2))
+                ts.add([[0], [H - 2], list(range(W)), [0]], group=0, use_target=False, axis=1, taps=taps(H))
+                ts.add([[0], list(range(H)), [W - 2], [0]], group=1, use_target=False, axis=2, taps=taps(W))
+                return ts
+            vx, vy = _term_means(x, None, _cached(("pbc", H, W), build), 2)
+            vx, vy = vx.to(torch.float32), vy.to(torch.float32)
+            losses[f"{name}_val_x"], losses[f"{name}_val_y"], losses[f"{name}_total"] = vx, vy, vx + vy
+            total = vx + vy if total is None else total + (vx + vy)
+        if total is None:
+            raise StopIteration("PeriodicBCLoss: no fields")
+        losses["total"] = total
+        return total, losses
+
+
 def compute_boundary_loss(pred, target, channel_mask, bc_width: int = 1, variant: Optional[str] = None) -> torch.Tensor:
     """The reference has one `compute_boundary_loss` per trainer; `variant` picks which
-    ('1d', 'strips', 'edges', 'faces', 'shells'); by default the tensor rank decides: 4 -> '1d', 5 -> 'strips', 6 -> 'shells'."""
+    ('1d', 'strips', 'edges', 'faces', 'shells', 'xy_strips'); by default the tensor rank decides: 4 -> '1d', 5 -> 'strips',
+    6 -> 'shells'.  'xy_strips' is what the 3-D Burgers trainer's copy computes on its 6-D tensors
+    (finetune/train_burgers_3d_apebench_lora.py:115-150); it is never picked by rank."""
     if variant is None:
         variant = {4: "1d", 5: "strips", 6: "shells"}.get(pred.dim())
     if variant == "1d":
@@ -263,6 +324,8 @@ def compute_boundary_loss(pred, target, channel_mask, bc_width: int = 1, variant
         return boundary_loss_3d_faces(pred, target, channel_mask)
     if variant == "shells":
         return boundary_loss_3d_shells(pred, target, channel_mask, bc_width)
+    if variant == "xy_strips":
+        return boundary_loss_3d_xy_strips(pred, target, channel_mask, bc_width)
     raise ValueError(f"compute_boundary_loss: unknown variant {variant!r} for a {pred.dim()}-d tensor")
 
 

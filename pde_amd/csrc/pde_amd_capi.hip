@@ -53,15 +53,26 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // One-shot timing hook (pde_amd_time_next_adjoint): the next launch of the vector adjoint kernel on this host thread is
 // bracketed by these two events on its own stream, nothing else of the call is.
 static thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+static thread_local bool t_ev_failed = false;      // a record of the pair failed: reported as PDE_AMD_EEVENT, not as a launch failure
 struct AdjointTimer {
   hipStream_t st;
   hipEvent_t e1;
   explicit AdjointTimer(hipStream_t s) : st(s), e1(t_ev1) {
-    if (t_ev0) (void)hipEventRecord(t_ev0, st);
+    t_ev_failed = false;
+    if (t_ev0 && hipEventRecord(t_ev0, st) != hipSuccess) { t_ev_failed = true; (void)hipGetLastError(); }
     t_ev0 = t_ev1 = nullptr;
   }
-  ~AdjointTimer() { if (e1) (void)hipEventRecord(e1, st); }
+  ~AdjointTimer() {
+    if (e1 && hipEventRecord(e1, st) != hipSuccess) { t_ev_failed = true; (void)hipGetLastError(); }
+  }
 };
+// status of a call whose launches are done: a failed launch first, then a failed timing-event record
+static inline int launch_status() {
+  const bool ev = t_ev_failed;
+  t_ev_failed = false;
+  if (hipGetLastError() != hipSuccess) return PDE_AMD_EHIP;
+  return ev ? PDE_AMD_EEVENT : PDE_AMD_OK;
+}
 
 // The register-blocked kernels move 16 bytes per lane: every pointer must be 16-byte aligned and the
 // fastest extent a multiple of 4.
@@ -274,7 +285,7 @@ struct Ops {
         }
       }
     }
-    if (fused) return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+    if (fused) return launch_status();
     st = fwd(p, fields, aux, sparams, weights, sums, totals, nullptr, ws, ws_bytes_given, stream);
     if (st) return st;
     const float* ups[MAXE + 1] = {};
@@ -358,7 +369,7 @@ struct Ops {
         return PDE_AMD_EINVAL;   // this PDE has no recomputing adjoint: pass the stored residuals
       }
     }
-    return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+    return launch_status();
   }
 
   static PdeVTable vtable() {
@@ -416,6 +427,7 @@ const char* pde_amd_status_string(int status) {
     case PDE_AMD_ESHAPE: return "unsupported shape";
     case PDE_AMD_EWORKSPACE: return "workspace too small";
     case PDE_AMD_EHIP: return "HIP launch failed";
+    case PDE_AMD_EEVENT: return "recording a timing event failed (pde_amd_time_next_adjoint); the kernels were launched";
     case PDE_AMD_ESCRATCH: return "problem needs more partial-sum scratch than PDE_AMD_STATIC_SCRATCH_BYTES";
     default: return "unknown status";
   }

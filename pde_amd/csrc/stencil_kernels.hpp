@@ -16,7 +16,7 @@ namespace pde_amd {
 
 constexpr int MAXF = 4;    // fields
 constexpr int MAXE = 4;    // equations
-constexpr int MAXA = 1;    // time-independent auxiliary fields
+constexpr int MAXA = 2;    // time-independent auxiliary fields
 constexpr int MAXSP = 3;   // per-sample parameters
 constexpr int MAXC = 16;   // per-instance constants
 

@@ -101,9 +101,12 @@ class StencilPDELoss(nn.Module):
 
     def _weights(self, T_res: int, n_sites: int, device, t_offset) -> Tuple[Tensor, List[bool]]:
         """wt[k, t] = w_k / (s^2 N) with s the fixed or per-timestep scale; zero rows for skipped equations."""
+        # eq_scales, eq_weights and the per-timestep buffers are public and mutable (a schedule on a weight, load_state_dict):
+        # their current values are part of the key, so a change takes effect on the next call, as in the reference
         key = (T_res, n_sites, str(device)) if t_offset is None else None
-        if key is not None and key in self._wt_cache:
-            return self._wt_cache[key]
+        state = self._scale_state() if key is not None else None
+        if key is not None and key in self._wt_cache and self._wt_cache[key][0] == state:
+            return self._wt_cache[key][1]
         rows, skipped = [], []
         for eq in self.EQS:
             k = self.SCALE_KEYS.get(eq, eq)
@@ -122,8 +125,13 @@ class StencilPDELoss(nn.Module):
         wt = torch.stack(rows).to(torch.float32) if rows else torch.zeros((0, max(T_res, 0)), device=device)
         out = (wt, skipped)
         if key is not None:
-            self._wt_cache[key] = out
+            self._wt_cache[key] = (state, out)      # one entry per shape: a newer state replaces the older one
         return out
+
+    def _scale_state(self) -> tuple:
+        bufs = tuple((n, b._version, b.data_ptr()) for n, b in self.named_buffers(recurse=False) if n.startswith("scales_t_"))
+        flag = bool(getattr(self, self.PER_T_FLAG, False))
+        return (tuple((k, float(v)) for k, v in self.eq_scales.items()), tuple((k, float(v)) for k, v in self.eq_weights.items()), flag, bufs)
 
     def _fixed_scale(self, eq: str) -> float:
         return float(self.eq_scales[self.SCALE_KEYS.get(eq, eq)])
@@ -330,6 +338,56 @@ class TaylorGreen2DPDELoss(StencilPDELoss):
 
     def forward(self, u: Tensor, v: Tensor, p: Tensor, nu: Optional[Tensor] = None, t_offset: Optional[Tensor] = None):
         return self._evaluate([u, v, p], [self._sample_param(nu, 0.01, u.shape[0], u)], t_offset=t_offset)   # :1853-1856
+
+
+class TaylorGreenPDELoss(TaylorGreen2DPDELoss):
+    """The 2-D class finetune/train_taylor_green_lora_v3.py:66 and tools/visualize_taylor_green_lora.py:34 import; the
+    reference snapshot no longer defines it.  Constructor and call as at those sites (:341-348 `nx, ny, Lx, Ly, dt, nu`,
+    :190 `forward(u, v, p, nu=nu)`); the arithmetic is that of its in-tree successor TaylorGreen2DPDELoss, with the
+    constructor's `nu` as the fallback when forward gets none.  No reference class pins it."""
+
+    def __init__(self, nx: int = 256, ny: int = 256, Lx: float = 6.283185307179586, Ly: float = 6.283185307179586,
+                 dt: float = 0.001, nu: float = 0.001, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__(nx, ny, Lx, Ly, dt, eq_scales, eq_weights, eq_scales_per_t)
+        self.nu = nu
+
+    def forward(self, u: Tensor, v: Tensor, p: Tensor, nu: Optional[Tensor] = None, t_offset: Optional[Tensor] = None):
+        return self._evaluate([u, v, p], [self._sample_param(nu, self.nu, u.shape[0], u)], t_offset=t_offset)
+
+
+class NSIncomPDELoss(StencilPDELoss):
+    """Forced incompressible Navier-Stokes with a tracer between no-slip walls (PDEBench ns_incom).
+
+    The reference snapshot imports this class (finetune/train_ns_incom_lora_v3.py:68; constructed at :417-428, called at
+    :223 as `forward(u, v, p, d, fx, fy)` with the time-invariant force fx, fy [B, H, W]) but does not define it.  The
+    arithmetic follows the n-PINN form ("Method B") of tools/test_gt_pde_ns_incom.py:258-378, which the trainer's header
+    (:4-8) names: face-velocity divergence; conservative 2nd-order upwind convection, c2 Laplacian, force d * f and the
+    div correction for u, v and the tracer; plus the face-averaged pressure gradient of that file's specification
+    (:109-111, :122-123), which its code leaves out because the data set stores no pressure.  x runs along dim -2, y along
+    dim -1; only sites `skip_bl` (>= 2) cells away from every wall enter.  Default scales: the values quoted at
+    configs/finetune_ns_incom_v3.yaml:119-126.  Pinned by that file's residual arrays, not by a reference class."""
+    SPEC, EQS = "ns_incom", ("continuity", "u_momentum", "v_momentum", "tracer")
+    GUARDED = ("u_momentum", "v_momentum", "tracer")
+    DEFAULT_EQ_SCALES = {"continuity": 7e-4, "u_momentum": 1.34, "v_momentum": 1.31, "tracer": 0.24}
+
+    def __init__(self, nx: int = 512, ny: int = 512, Lx: float = 1.0, Ly: float = 1.0, dt: float = 0.005, nu: float = 0.01,
+                 skip_bl: int = 2, use_div_correction: bool = True, eq_scales=None, eq_weights=None):
+        super().__init__()
+        if int(skip_bl) < 2:
+            raise ValueError("NSIncomPDELoss: skip_bl must be at least 2 (the upwind fluxes reach two cells)")
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.nu, self.skip_bl = Lx / nx, Ly / ny, dt, nu, int(skip_bl)
+        self.use_div_correction = use_div_correction
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, nu=self.nu, div_corr=1.0 if self.use_div_correction else 0.0)
+
+    def _lattice(self, spatial):
+        return (0, self.skip_bl, self.skip_bl), (0, self.skip_bl, self.skip_bl)
+
+    def forward(self, u: Tensor, v: Tensor, p: Tensor, d: Tensor, fx: Tensor, fy: Tensor):
+        return self._evaluate([u, v, p, d], aux=[fx, fy])
 
 
 class AdvDiff2DPDELoss(StencilPDELoss):
@@ -736,6 +794,30 @@ class Heat3DPDELoss(StencilPDELoss):
 
     def forward(self, u: Tensor, alpha: Optional[Tensor] = None):
         return self._evaluate([u], [self._sample_param(alpha, self.alpha, u.shape[0], u)])
+
+
+class TaylorGreen3DPDELoss(StencilPDELoss):
+    """3-D Taylor-Green vortex: face-velocity divergence and the three c2 primitive-form momentum equations, periodic,
+    per-sample nu; fields u, v, w, p [B, T, X, Y, Z].
+
+    The reference has no such class; the arithmetic is that of its in-tree verifier `verify_3d_taylor_green`
+    (finetune/generate_analytical_3d.py:97-157), which spells out the divergence and the u momentum (v and w are the same
+    with the axes permuted); all four are evaluated on the interior frames.  Pinned by that function's outputs."""
+    SPEC, EQS = "tg3d", ("continuity", "u_momentum", "v_momentum", "w_momentum")
+    DEFAULT_EQ_SCALES = {"continuity": 1.0, "u_momentum": 1.0, "v_momentum": 1.0, "w_momentum": 1.0}
+
+    def __init__(self, nx: int = 64, ny: int = 64, nz: int = 64, Lx: float = 2 * np.pi, Ly: float = 2 * np.pi,
+                 Lz: float = 2 * np.pi, dt: float = 0.01, nu: float = 0.01, eq_scales=None, eq_weights=None):
+        super().__init__()
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.dx, self.dy, self.dz, self.dt, self.nu = Lx / nx, Ly / ny, Lz / nz, dt, nu
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, None, per_t_supported=False)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dz=self.dz, dt=self.dt)
+
+    def forward(self, u: Tensor, v: Tensor, w: Tensor, p: Tensor, nu: Optional[Tensor] = None):
+        return self._evaluate([u, v, w, p], [self._sample_param(nu, self.nu, u.shape[0], u)])
 
 
 # =================================================================================================

@@ -88,15 +88,14 @@ class LpLoss:
     p = 2 is one pass of the statistics kernel over both tensors; other p use device-side torch reductions."""
 
     def __init__(self, p=2, reduction="mean"):
-        assert p > 0
+        if not p > 0:
+            raise AssertionError("the norm order p must be positive")
         self.p, self.reduction = p, reduction
 
     def _reduce(self, r):
-        if self.reduction in ["mean"]:
-            return torch.mean(r)
-        if self.reduction in ["sum"]:
-            return torch.sum(r)
-        return r
+        """per-example ratios -> their mean / sum, or the ratios themselves for any other reduction string"""
+        fold = {"mean": torch.mean, "sum": torch.sum}.get(self.reduction)
+        return r if fold is None else fold(r)
 
     def _ratio(self, x, y, eps):
         n = x.size()[0]
@@ -164,7 +163,11 @@ class NRMSEAccumulator:
     def update(self, pred, target, channel_mask):
         B, T = int(pred.shape[0]), int(pred.shape[1])
         G, rows, C = _flat(pred, target, 2)
-        st = R.get_backend().pair_stats(pred, target, G, rows, C).view(B, T, C, R.NSTAT)
+        if isinstance(pred, Denormalised):      # std and mean applied while reading: one value per (sample, channel), repeated per frame
+            affine = (pred.scale.repeat_interleave(T, 0), pred.shift.repeat_interleave(T, 0))
+            st = R.get_backend().pair_stats(pred.base.detach(), target, G, rows, C, affine=affine).view(B, T, C, R.NSTAT)
+        else:
+            st = R.get_backend().pair_stats(pred, target, G, rows, C).view(B, T, C, R.NSTAT)
         s = st[..., [R.S_D2, R.S_G2]].sum(0)                     # [T, C, 2]
         if self.sums is None:
             self.sums = s

@@ -463,10 +463,51 @@ def _heat3d():
     return b.done([_ddt(b, u) - al * lap], **T3D)
 
 
+def _tg3d():
+    # No class of this name exists in the reference snapshot; arithmetic follows verify_3d_taylor_green,
+    # finetune/generate_analytical_3d.py:97-157 (x, y, z = dims -3, -2, -1): face-velocity divergence, and for each velocity
+    # component the c2 primitive-form momentum R = phi_t + u phi_x + v phi_y + w phi_z + p_(own axis) - nu lap2(phi)
+    # (the verifier spells out the u component only), per-sample nu
+    b = _B("tg3d", 3, ["u", "v", "w", "p"], ["continuity", "u_momentum", "v_momentum", "w_momentum"])
+    u, v, w, p = b.F()
+    nu = b.s("nu")
+    hs = ("dx", "dy", "dz")
+    inv = [b.c("inv_" + h, _inv(h)) for h in hs]
+    face = lambda q, ax: 0.5 * (sh(q, ax, 1) + q) - 0.5 * (sh(q, ax, -1) + q)
+    div = face(u, 0) * inv[0] + face(v, 1) * inv[1] + face(w, 2) * inv[2]
+    lap = lambda q: _d2c2(b, q, 0, "dx") + _d2c2(b, q, 1, "dy") + _d2c2(b, q, 2, "dz")
+    res = [div]
+    for ax, phi in enumerate((u, v, w)):
+        conv = u * _d1c2(b, phi, 0, "dx") + v * _d1c2(b, phi, 1, "dy") + w * _d1c2(b, phi, 2, "dz")
+        res.append(_ddt(b, phi) + conv + _d1c2(b, p, ax, hs[ax]) - nu * lap(phi))
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16)})
+
+
+def _ns_incom():
+    # No class of this name exists in the reference snapshot (finetune/train_ns_incom_lora_v3.py:68 imports it); arithmetic
+    # follows "Method B" of tools/test_gt_pde_ns_incom.py:258-378 (n-PINN: face velocities, 2nd-order upwind conservative
+    # fluxes, c2 Laplacian, div correction, time-invariant force fx, fy times the tracer; x = dim -2, y = dim -1) plus the
+    # face-averaged pressure gradient of its specification (:109-111, :122-123).  Walls on both axes: the residual lattice
+    # is [skip, N - skip), skip >= 2
+    b = _B("ns_incom", 2, ["u", "v", "p", "d"], ["continuity", "u_momentum", "v_momentum", "tracer"],
+           periodic=(True, False, False), aux_names=["fx", "fy"])
+    u, v, p, d = b.F()
+    fx, fy = b.A(0), b.A(1)
+    div, conv, lap = _npinn_parts(b, u, v, 1, 2)
+    idx, idy = b.c("inv_dx", _inv("dx")), b.c("inv_dy", _inv("dy"))
+    nu, dc = b.c("nu", _k("nu")), b.c("div_corr", _k("div_corr"))
+    px = (0.5 * (p + sh(p, 1, 1)) - 0.5 * (sh(p, 1, -1) + p)) * idx
+    py = (0.5 * (p + sh(p, 2, 1)) - 0.5 * (sh(p, 2, -1) + p)) * idy
+    ru = _ddt(b, u) + conv(u) + px - nu * lap(u) - d * fx - dc * u * div
+    rv = _ddt(b, v) + conv(v) + py - nu * lap(v) - d * fy - dc * v * div
+    rd = _ddt(b, d) + conv(d) - dc * d * div
+    return b.done([div, ru, rv, rd], **{**T2D_WIDE, 'quad_bwd': (1, 16, 32)})
+
+
 for _f in (_burgers1d, _advection1d, _heat1d, _ape_burgers1d, _ks1d, _kdv1d, _tg2d, _advdiff2d, _anisodiff2d,
            _wave2d, _ape_burgers2d, _nspwc, _kp2d, _shear_flow, _burgers2d_ch, _active_matter,
            _rayleigh_benard, _turbulent_radiative, _wave_gauss, _burgers2d_ghost, _gray_scott_fd,
-           _gray_scott_pw, _advection3d, _ape_burgers3d, _swift_hohenberg3d, _heat3d):
+           _gray_scott_pw, _advection3d, _ape_burgers3d, _swift_hohenberg3d, _heat3d, _tg3d, _ns_incom):
     _reg(_f())
 
 PDE_IDS = {name: i for i, name in enumerate(SPECS)}

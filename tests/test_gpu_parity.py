@@ -31,7 +31,7 @@ def _run(mod, fields, extra):
     return total, losses, [f.grad for f in fields]
 
 
-@pytest.mark.parametrize("mode", ["auto", "stored"])
+@pytest.mark.parametrize("mode", ["auto", "stored", "fused"])      # fused falls back to stored where the PDE cannot recompute
 @pytest.mark.parametrize("name", golden_cases())
 def test_golden(name, mode):
     dev = _dev()

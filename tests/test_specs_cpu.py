@@ -139,3 +139,30 @@ def test_fused_mode_host_logic():
             for a, b, c in zip(ga, g1, g2):
                 assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
                 assert float((a - c).abs().max()) <= 1e-6 * float(a.abs().max())
+
+
+def test_scales_and_weights_changed_after_the_first_call_take_effect():
+    """eq_scales / eq_weights / the per-timestep buffers are re-read on every call, as in the reference"""
+    g = torch.Generator().manual_seed(8)
+    fields = [torch.randn(2, 5, 8, 8, generator=g) for _ in range(3)]
+    nu = torch.tensor([0.02, 0.05])
+    per_t = {"continuity": torch.tensor([1.0, 2.0, 3.0, 4.0])}
+    mod = PL.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01, eq_scales_per_t={k: v.clone() for k, v in per_t.items()})
+    ref = OC.build("TaylorGreen2DPDELoss", nx=8, ny=8, dt=0.01, eq_scales_per_t=per_t)
+    f64 = [f.double() for f in fields]
+
+    def same():
+        a, _ = mod(*fields, nu=nu)
+        b, _ = ref(*f64, nu=nu.double())
+        assert abs(float(a) - float(b)) <= 3e-6 * abs(float(b))
+        return float(a)
+
+    v0 = same()
+    mod.eq_scales["x_momentum"] = ref.scales["x_momentum"] = 3.0
+    v1 = same()
+    mod.eq_weights["y_momentum"] = ref.weights["y_momentum"] = 0.0      # now a skipped (guarded) equation
+    v2 = same()
+    mod.scales_t_continuity.mul_(2.0)
+    ref.per_t_bufs["continuity"] = ref.per_t_bufs["continuity"] * 2.0
+    v3 = same()
+    assert len({v0, v1, v2, v3}) == 4

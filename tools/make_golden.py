@@ -298,11 +298,173 @@ def run_metric_func():
     return out
 
 
+def load_class(path, name, extra_globals=None):
+    """Compile ONE top-level class out of a reference script whose module-level imports are unavailable."""
+    src = open(os.path.join(REF, path)).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == name:
+            glb = {"torch": torch, "nn": torch.nn, "np": np, "Dict": __import__("typing").Dict,
+                   "Tuple": __import__("typing").Tuple, "Optional": __import__("typing").Optional}
+            glb.update(extra_globals or {})
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), glb)
+            return glb[name]
+    raise KeyError(name)
+
+
+def run_pins():
+    """Fixtures from the reference's own verification code for what has no class in the reference tree (or lives inside
+    a driver loop): the FD-c4 Gray-Scott residuals, the 3-D heat and 3-D Taylor-Green verifiers, the n-PINN residuals of
+    the inhomogeneous incompressible NS test, the periodic-BC loss, the eval_nrmse loop, and the boundary loss that the
+    3-D Burgers trainer applies to a 6-D tensor."""
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+    rnd = lambda *shape: torch.randn(*shape, generator=g, dtype=torch.float64)
+
+    # -- Gray-Scott FD-c4: tools/test_gt_pde_gray_scott.py:27-79 (NumPy, one sample [T, H, W] at a time)
+    lap = load_function("tools/test_gt_pde_gray_scott.py", "fd_laplacian_4th")
+    res = load_function("tools/test_gt_pde_gray_scott.py", "compute_residuals", dict(fd_laplacian_4th=lap))
+    A, Bq = _fields((2, 5, 12, 10), 2, 41)
+    par = dict(dx=0.11, dy=0.07, dt=10.0, F=0.098, k=0.057, D_A=1.81e-5, D_B=1.39e-5)
+    rs = [res(A[i].numpy(), Bq[i].numpy(), **par) for i in range(2)]
+    out["gsfd_A"], out["gsfd_B"] = A.numpy(), Bq.numpy()
+    out["gsfd_params"] = np.frombuffer(json.dumps(par).encode(), dtype=np.uint8)
+    out["gsfd_R_A"] = np.stack([r["A_equation"] for r in rs])
+    out["gsfd_R_B"] = np.stack([r["B_equation"] for r in rs])
+
+    # -- heat 3-D: finetune/generate_analytical_3d.py:160-178 (mean squared residual of one sample [T, X, Y, Z])
+    vh = load_function("finetune/generate_analytical_3d.py", "verify_3d_heat")
+    (u,) = _fields((2, 5, 6, 5, 7), 1, 42)
+    par = dict(dx=0.2, dy=0.3, dz=0.25, dt=0.01)
+    alpha = [0.013, 0.041]
+    out["heat3d_u"], out["heat3d_alpha"] = u.numpy(), np.asarray(alpha)
+    out["heat3d_params"] = np.frombuffer(json.dumps(par).encode(), dtype=np.uint8)
+    out["heat3d_mse"] = np.asarray([vh(u[i].numpy(), alpha[i], **par) for i in range(2)])
+
+    # -- Taylor-Green 3-D: finetune/generate_analytical_3d.py:97-157 (face-velocity divergence on every frame,
+    #    c2 primitive-form u momentum on interior frames)
+    vt = load_function("finetune/generate_analytical_3d.py", "verify_3d_taylor_green")
+    u3, v3, w3, p3 = _fields((2, 5, 6, 5, 7), 4, 43)
+    nu3 = [0.02, 0.07]
+    for n, f in zip("uvwp", (u3, v3, w3, p3)):
+        out[f"tg3d_{n}"] = f.numpy()
+    out["tg3d_nu"] = np.asarray(nu3)
+    out["tg3d_params"] = np.frombuffer(json.dumps(par).encode(), dtype=np.uint8)
+    r = [vt(u3[i].numpy(), v3[i].numpy(), w3[i].numpy(), p3[i].numpy(), nu3[i], **par) for i in range(2)]
+    out["tg3d_div_mse"] = np.asarray([x["div"] for x in r])
+    out["tg3d_u_momentum_mse"] = np.asarray([x["u_momentum"] for x in r])
+
+    # -- incompressible NS with forcing, n-PINN form: tools/test_gt_pde_ns_incom.py:258-428.  The function only returns
+    #    RMS values; its `rms` helper is replaced by one that also keeps the array it is given, in call order:
+    #    div, R_u, du_dt, R_v, dv_dt, R_d, dd_dt, ...
+    kept = []
+
+    def rms(x):
+        kept.append(np.array(x))
+        return float(np.sqrt(np.mean(x ** 2)))
+    mb = load_function("tools/test_gt_pde_ns_incom.py", "method_b_npinn_conservative", dict(rms=rms))
+    vx, vy, dd = _fields((2, 5, 12, 10), 3, 44)
+    fx, fy = rnd(2, 12, 10), rnd(2, 12, 10)
+    par = dict(dx=0.09, dy=0.13, dt=0.005, nu=0.01, skip=2)
+    for n, f in (("vx", vx), ("vy", vy), ("d", dd), ("fx", fx), ("fy", fy)):
+        out[f"nsincom_{n}"] = f.numpy()
+    out["nsincom_params"] = np.frombuffer(json.dumps(par).encode(), dtype=np.uint8)
+    rows = {k: [] for k in ("div", "R_u", "R_v", "R_d")}
+    scal = {k: [] for k in ("cont_rms", "mom_x_rms", "mom_y_rms", "tracer_rms")}
+    for i in range(2):
+        kept.clear()
+        r = mb(vx[i].numpy(), vy[i].numpy(), dd[i].numpy(), fx[i].numpy(), fy[i].numpy(), **par)
+        rows["div"].append(kept[0]); rows["R_u"].append(kept[1]); rows["R_v"].append(kept[3]); rows["R_d"].append(kept[5])
+        for k in scal:
+            scal[k].append(r[k])
+    for k, v in rows.items():
+        out[f"nsincom_{k}"] = np.stack(v)
+    for k, v in scal.items():
+        out[f"nsincom_{k}"] = np.asarray(v)
+
+    # -- periodic-BC loss: tools/test_gt_periodic_bc.py:38-105
+    PBC = load_class("tools/test_gt_periodic_bc.py", "PeriodicBCLoss")
+    fa, fb = rnd(2, 3, 9, 8).requires_grad_(True), rnd(2, 3, 9, 8).requires_grad_(True)
+    tot, d = PBC(dx=0.1, dy=0.2)({"u": fa, "s": fb})
+    tot.backward()
+    out["pbc_u"], out["pbc_s"] = fa.detach().numpy(), fb.detach().numpy()
+    out["pbc_total"] = tot.detach().numpy()
+    out["pbc_keys"] = np.frombuffer(json.dumps(list(d)).encode(), dtype=np.uint8)
+    out["pbc_values"] = np.asarray([float(v) for v in d.values()])
+    out["pbc_grad_u"], out["pbc_grad_s"] = fa.grad.numpy(), fb.grad.numpy()
+
+    # -- eval_nrmse.evaluate: eval/eval_nrmse.py:74-212 around a stub model / dataloader / accelerator
+    class _Acc:
+        device = torch.device("cpu")
+
+        def wait_for_everyone(self):
+            pass
+
+        def reduce(self, t, reduction="sum"):
+            return t
+
+    t_input, C = 3, 18
+    batches, preds = [], []
+    mask = torch.zeros(2, C)
+    mask[:, [0, 4, 15]] = 1.0
+    for _ in range(3):
+        data = torch.randn(2, t_input + 1, 6, 5, C, generator=g)
+        batches.append({"data": data, "channel_mask": mask})
+        preds.append((torch.randn(2, t_input, 6, 5, C, generator=g), torch.randn(2, 1, 1, 1, C, generator=g),
+                      0.5 + torch.rand(2, 1, 1, 1, C, generator=g)))
+
+    class _Model:
+        def __init__(self):
+            self.i = 0
+
+        def eval(self):
+            pass
+
+        def train(self):
+            pass
+
+        def __call__(self, x, return_normalized=True):
+            r = preds[self.i]
+            self.i += 1
+            return r
+    ev = load_function("eval/eval_nrmse.py", "evaluate", dict(Accelerator=object))
+    r = ev(_Model(), batches, _Acc(), t_input, per_timestep=True)
+    out["nrmse_data"] = np.stack([b["data"].numpy() for b in batches])
+    out["nrmse_mask"] = mask.numpy()
+    out["nrmse_out_norm"] = np.stack([p[0].numpy() for p in preds])
+    out["nrmse_mean"] = np.stack([p[1].numpy() for p in preds])
+    out["nrmse_std"] = np.stack([p[2].numpy() for p in preds])
+    chs = sorted(r["per_channel_nrmse"])
+    out["nrmse_channels"] = np.asarray(chs)
+    for k in ("per_channel_nrmse", "per_channel_rmse", "per_channel_gt_rms"):
+        out[f"nrmse_{k}"] = np.asarray([r[k][c] for c in chs])
+    out["nrmse_overall"] = np.asarray(r["overall_nrmse"])
+    out["nrmse_num_samples"] = np.asarray(r["num_samples"])
+    out["nrmse_per_timestep"] = np.asarray([r["per_timestep_nrmse"][c] for c in chs])
+
+    # -- the 2-D strip loss applied to a 6-D tensor: finetune/train_burgers_3d_apebench_lora.py:115-150
+    #    (the channel list indexes the Z axis, all channels are kept; Z must exceed the largest valid channel)
+    f = load_function("finetune/train_burgers_3d_apebench_lora.py", "compute_boundary_loss")
+    m6 = torch.zeros(6)
+    m6[[0, 1, 2]] = 1.0
+    p6, t6 = rnd(2, 2, 6, 5, 4, 6), rnd(2, 2, 6, 5, 4, 6)
+    out["bc6d_pred"], out["bc6d_target"], out["bc6d_mask"] = p6.numpy(), t6.numpy(), m6.numpy()
+    for w in (1, 2):
+        q = p6.clone().requires_grad_(True)
+        val = f(q, t6, m6, w)
+        val.backward()
+        out[f"bc6d_w{w}"], out[f"bc6d_w{w}_grad"] = val.detach().numpy(), q.grad.numpy()
+    return out
+
+
 def main():
     sys.path.insert(0, REF)
     import finetune.pde_loss_verified as mod
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if "--only-pins" in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "pins.npz"), **run_pins())
+        print("wrote pins")
+        return
     if "--only-glue" in sys.argv:
         np.savez_compressed(os.path.join(OUT, "glue.npz"), **run_glue())
         print("wrote glue")
@@ -314,6 +476,8 @@ def main():
     print("wrote burgers2d_ghost")
     np.savez_compressed(os.path.join(OUT, "glue.npz"), **run_glue())
     print("wrote glue")
+    np.savez_compressed(os.path.join(OUT, "pins.npz"), **run_pins())
+    print("wrote pins")
     try:
         np.savez_compressed(os.path.join(OUT, "metric_func.npz"), **run_metric_func())
         print("wrote metric_func")
