@@ -717,7 +717,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 #pragma unroll
         for (int f = 0; f < P::NF; ++f) gs[px][f] = 0.0f;
 #ifndef PDE_AMD_ABL_NO_GATHER
-      if (do_space)
+      if (do_space && gvalid)      // G(n) is identically zero on frames without a residual: nothing to gather
 #else
       if (do_space && a.chunk < 0)
 #endif
