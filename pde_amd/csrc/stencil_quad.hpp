@@ -1020,7 +1020,9 @@ struct StoredCfg {
   using TX = Tile<P::QB0, P::QB1, P::QB2, P::XH0, P::XH1, padw<W>(P::XH2)>;
   static constexpr bool GT_ON = (P::GT0 | P::GT1 | P::GT2) != 0;
   static constexpr int NGT = P::GTLO + P::GTHI;
-  static constexpr long BYTES = 4L * (P::NE * TG::SIZE + (GT_ON ? NGT * P::NE * TGT::SIZE : 0) + (P::ANY_AF ? P::NF * TA::SIZE : 0) +
+  // fields that the adjoint reads at the output point only (no spatial reach) stay in registers: no tile
+  static constexpr bool AF_TILE = P::ANY_AF != 0 && (P::AH0 | P::AH1 | P::AH2) != 0;
+  static constexpr long BYTES = 4L * (P::NE * TG::SIZE + (GT_ON ? NGT * P::NE * TGT::SIZE : 0) + (AF_TILE ? P::NF * TA::SIZE : 0) +
                                       (P::NA ? P::NA * TX::SIZE : 0));
   static constexpr bool OK = P::ATLO == 0 && P::ATHI == 0 && (P::AT0 | P::AT1 | P::AT2) == 0 && BYTES <= LDS_BUDGET && P::QB2 % W == 0 &&
                              (P::QB0 * P::QB1 * (P::QB2 / W)) % NT == 0 && NT % (P::QB2 / W) == 0 && NT <= 1024;
@@ -1035,6 +1037,7 @@ struct StoredAdjAccQ : SiteBase<P> {
   const float* ldsa;
   const float* ldsx;
   fv gc[NG][MAXE];           // this quad's G at the other frames when those terms need no halo
+  fv fq[MAXF];               // this quad's fields when the adjoint reads them at the output point only
   int px;
   __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
     if (ot == 0) {
@@ -1051,6 +1054,7 @@ struct StoredAdjAccQ : SiteBase<P> {
     return gc[ot + P::GTLO][k][px];
   }
   __device__ __forceinline__ float F(int f, int, int o0, int o1, int o2) const {
+    if ((P::AH0 | P::AH1 | P::AH2) == 0) return fq[f][px];
     PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
     const fv v = *reinterpret_cast<const fv*>(ldsa + f * TA::SIZE + o0 * TA::S0 + o1 * TA::S1 + W * qd);
     return v[e];
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
   using TA = typename C::TA;
   using TX = typename C::TX;
   using fv = typename VecOf<W>::type;
-  constexpr bool GT_ON = C::GT_ON, AF_ON = P::ANY_AF != 0, AUX_ON = P::NA > 0;
+  constexpr bool GT_ON = C::GT_ON, AF_ON = C::AF_TILE, AF_REG = P::ANY_AF != 0 && !C::AF_TILE, AUX_ON = P::NA > 0;
   constexpr int NT = C::NT, NGT = C::NGT, NG = P::GTLO + P::GTHI + 1;
   constexpr int QR = TG::T2 / W;
   constexpr int QPT = (TG::T0 * TG::T1 * QR) / NT;
@@ -1133,7 +1137,8 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
     for (int f = 0; f < P::NF; ++f) msa.fetch(f, a.f[f] + frame);
   }
   fv gcq[QPT][NG][P::NE];
-  if (!GT_ON) {
+  fv fqq[QPT][P::NF];
+  if (!GT_ON || AF_REG) {
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
       const int row = (threadIdx.x / QR) * QPT + q;
@@ -1141,9 +1146,13 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
       const int i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
       const bool inside = i0 < g.N0 && i1 < g.N1 && i2 < g.N2;
       const long goff = inside ? ((long)i0 * g.N1 + i1) * g.N2 + i2 : 0;
+      if (AF_REG) {
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) fqq[q][f] = *reinterpret_cast<const fv*>(a.f[f] + frame + goff);
+      }
 #pragma unroll
       for (int s = 0; s < NG; ++s) {
-        if (s == P::GTLO) continue;
+        if (GT_ON || s == P::GTLO) continue;
         const int trs = max(min(tr0 + s - P::GTLO, g.TR - 1), 0);
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) gcq[q][s][k] = *reinterpret_cast<const fv*>(rp[k] + (long)trs * g.S + goff);
@@ -1198,6 +1207,10 @@ __global__ __launch_bounds__((StoredCfg<P, W>::NT)) void bwd_stored_q_kernel(con
             acc.gc[s][k] = cfk != 0.0f ? gcq[q][s][k] * cfk : vec_zero<W>();
           }
         }
+      }
+      if (AF_REG) {
+#pragma unroll
+        for (int f = 0; f < P::NF; ++f) acc.fq[f] = fqq[q][f];
       }
       fv out[P::NF];
 #pragma unroll
