@@ -2,6 +2,7 @@
 #include "../../include/pde_amd.h"
 #include "stencil_kernels.hpp"
 #include "stencil_quad.hpp"
+#include "stencil_zmarch.hpp"
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
@@ -104,6 +105,20 @@ static inline int pick_chunk(long blocks_per_chunking, int frames) {
   return chunk;
 }
 
+// Planes per workgroup of the plane-marching 3-D kernels: a chunk re-reads the 2 * reach planes before its first one, so
+// chunks are as long as still leaves the chip a few rounds of workgroups, and never shorter than 8 planes.
+static inline int pick_plane_chunk(long blocks_per_chunking, int planes) {
+#ifdef PDE_AMD_DIAG_ONLY
+  if (getenv("PDE_AMD_ZCHUNK")) return atoi(getenv("PDE_AMD_ZCHUNK"));
+#endif
+  const long want = 4 * 768;
+  int nchunk = (int)((want + blocks_per_chunking - 1) / blocks_per_chunking);
+  if (nchunk < 1) nchunk = 1;
+  int chunk = cdiv(planes, nchunk);
+  if (chunk < 8) chunk = planes < 8 ? planes : 8;
+  return chunk;
+}
+
 template <class P>
 struct Ops {
   static void fill_geom(const pde_amd_problem* p, Geom& g, int t0, int t1, int t2) {
@@ -178,6 +193,14 @@ struct Ops {
         a.rout[k] = resid_out[k];
       }
       bool launched = false;
+      if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && ZCfg<P, P::ZW>::FWD_OK) {
+        if (p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NE, P::ZW>(resid_out)) {
+          items = launch_plane_forward<true>(p, a, tr, stream);
+          if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+          if (items < 0) return PDE_AMD_ESHAPE;
+          launched = true;
+        }
+      }
       if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
         if (quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
             (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
@@ -205,6 +228,12 @@ struct Ops {
         items = tr * tiles;
         if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
         hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
+      }
+    } else if (!QuadCfg<P, P::QWF>::FWD_OK && ZCfg<P, P::ZW>::FWD_OK && p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields)) {
+      if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && ZCfg<P, P::ZW>::FWD_OK) {
+        items = launch_plane_forward<false>(p, a, tr, stream);
+        if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+        if (items < 0) return PDE_AMD_ESHAPE;
       }
     } else if (QuadCfg<P, P::QWF>::FWD_OK && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
                (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
@@ -237,6 +266,22 @@ struct Ops {
     }
     reduce_partials(a.partial, sums, totals, items, p->batch, stream);
     return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+  }
+
+  // Plane-marching forward of a 3-D PDE; returns the partial sums per sample (< 0: too many workgroups).
+  template <bool WRITE_R>
+  static long launch_plane_forward(const pde_amd_problem* p, Args& a, long tr, hipStream_t stream) {
+    if constexpr (ZCfg<P, P::ZW>::FWD_OK) {
+      using C = ZCfg<P, P::ZW>;
+      const long yx = (long)cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
+      a.chunk = pick_plane_chunk(p->batch * tr * yx, p->n[0]);
+      fill_geom(p, a.geo, a.chunk, C::T1, C::T2);
+      const long items = tr * a.geo.nt0 * yx;
+      if (p->batch * items >= (1L << 31)) return -1;
+      hipLaunchKernelGGL((fwd_zmarch_kernel<P, P::ZW, WRITE_R>), dim3((unsigned)(p->batch * items)), dim3(C::NT), 0, stream, a);
+      return items;
+    }
+    return -1;
   }
 
   static void reduce_partials(const double* partial, double* sums, float* totals, long items, int batch, hipStream_t stream) {
@@ -328,7 +373,20 @@ struct Ops {
         a.r[k] = resid_in[k];
       }
       bool launched = false;
+      if constexpr (ZCfg<P, P::ZW>::BWD_OK) {
+        if (p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NF, P::ZW>(grads) && aligned_vec<P::NE, P::ZW>(resid_in)) {
+          using C = ZCfg<P, P::ZW>;
+          const long yx = (long)cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
+          a.chunk = pick_plane_chunk(p->batch * p->frames * yx, p->n[0]);
+          fill_geom(p, a.geo, a.chunk, C::T1, C::T2);
+          const long nwgz = (long)p->batch * p->frames * a.geo.nt0 * yx;
+          if (nwgz >= (1L << 31)) return PDE_AMD_ESHAPE;
+          hipLaunchKernelGGL((bwd_stored_zmarch_kernel<P, P::ZW>), dim3((unsigned)nwgz), dim3(C::NT), 0, stream, a);
+          launched = true;
+        }
+      }
       if constexpr (StoredCfg<P, P::QWB>::OK) {
+        if (!launched)
         if (quad_addressable(p) && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) && aligned_vec<P::NF, P::QWB>(grads) &&
             aligned_vec<P::NE, P::QWB>(resid_in) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
           fill_geom(p, a.geo, P::QB0, P::QB1, P::QB2);

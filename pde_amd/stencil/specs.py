@@ -49,6 +49,10 @@ class Spec:
     quad_width_fwd: int = 4
     quad_width_bwd: int = 4
     waves_per_simd_quad_fwd: int = 1    # forward quad kernel: compile for this many waves per SIMD (1 = no constraint)
+    # plane-marching 3-D kernels (csrc/stencil_zmarch.hpp): (y, x) tile, lanes and lane width; (0, 0) = not used
+    z_tile: Tuple[int, int] = (0, 0)
+    z_threads: int = 256
+    z_width: int = 2
     hoist_uniforms: bool = True     # precompute products/sums of constants and per-sample parameters once per sample
     quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
 
@@ -125,6 +129,7 @@ def _reg(s: Spec):
 
 T1D = dict(tile_fwd=(1, 1, 256), tile_bwd=(1, 1, 256), threads=256, quad_fwd=(1, 1, 256), quad_bwd=(1, 1, 256), threads_quad=64)
 T3D = dict(tile_fwd=(2, 4, 64), tile_bwd=(4, 8, 64), threads=256, quad_fwd=(2, 8, 64), quad_bwd=(2, 8, 64), threads_quad=256)
+Z3D = dict(z_tile=(16, 32), z_threads=256, z_width=2)      # plane-marching kernels: 16 x 32 tile, a pair of points per lane
 T2D_WIDE = dict(tile_fwd=(1, 8, 64), tile_bwd=(1, 8, 64), quad_fwd=(1, 8, 64), quad_bwd=(1, 8, 64), threads_quad=128, quad_width_fwd=2, quad_width_bwd=2, quad_prefetch=1)   # 4-field PDEs
 
 
@@ -438,7 +443,7 @@ def _ape_burgers3d():
         res.append(_ddt(b, phi) + b1 * conv - a2 * lap(phi))
     # per-frame kernels (the time ring of 3-D halo tiles does not fit LDS): a near-cubic tile reads 3.4 halo floats per
     # point instead of 5.1 and leaves room for three workgroups per CU
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16)})
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D})
 
 
 def _swift_hohenberg3d():
@@ -480,7 +485,7 @@ def _tg3d():
     for ax, phi in enumerate((u, v, w)):
         conv = u * _d1c2(b, phi, 0, "dx") + v * _d1c2(b, phi, 1, "dy") + w * _d1c2(b, phi, 2, "dz")
         res.append(_ddt(b, phi) + conv + _d1c2(b, p, ax, hs[ax]) - nu * lap(phi))
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16)})
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D})
 
 
 def _ns_incom():

@@ -17,3 +17,29 @@ for m in re.finditer(r"^(_Z\w+):\s*;", s, flags=re.M):
         mm = re.search(p + r":\s+(\d+)", meta.group(1)) if meta else None
         out.append("%s %s" % (k, mm.group(1) if mm else "?"))
     print("  ".join(out))
+
+# with a second argument (substring of a kernel name): the instruction mix of every loop of the matching kernels
+if len(sys.argv) > 2:
+    for m in re.finditer(r"^(_Z\w+):\s*;", s, flags=re.M):
+        n = m.group(1)
+        if sys.argv[2] not in n:
+            continue
+        lines = [l.strip() for l in s[m.start():s.index("s_endpgm", m.start())].split("\n")]
+        labels = {}
+        for i, l in enumerate(lines):
+            mm = re.match(r"^(\.LBB\d+_\d+):", l)
+            if mm:
+                labels[mm.group(1)] = i
+        print(n[12:90])
+        for i, l in enumerate(lines):
+            mm = re.match(r"^s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+            if not mm or mm.group(1) not in labels or labels[mm.group(1)] >= i:
+                continue
+            seg = [x for x in lines[labels[mm.group(1)]:i + 1] if x and x[0] not in ".;" and not x.endswith(":")]
+            cnt = {}
+            for x in seg:
+                op = x.split()[0]
+                k = ("valu" if op.startswith("v_") else "ds" if op.startswith("ds_") else "vmem" if op.startswith(("global_", "buffer_", "flat_"))
+                     else "wait" if op.startswith(("s_waitcnt", "s_barrier", "s_nop")) else "salu")
+                cnt[k] = cnt.get(k, 0) + 1
+            print("  loop %s: %d instructions  %s" % (mm.group(1), len(seg), "  ".join("%s %d" % kv for kv in sorted(cnt.items()))))

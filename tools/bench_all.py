@@ -48,6 +48,7 @@ CASES = [
     ("TurbulentRadiative", "TurbulentRadiativePDELoss", dict(), (16, 9, 128, 384), lambda B: {}),
     ("C5 Heat3D B=2", "Heat3DPDELoss", dict(), (2, 9, 128, 128, 128), lambda B: dict(alpha=U(B, 0.005, 0.05))),
     ("C5 Burgers3D B=1", "APEBenchBurgers3DPDELoss", dict(), (1, 9, 128, 128, 128), lambda B: {}),
+    ("TaylorGreen3D B=1", "TaylorGreen3DPDELoss", dict(), (1, 9, 128, 128, 128), lambda B: dict(nu=U(B, 0.01, 0.1))),
     ("Advection3D B=2", "Advection3DPDELoss", dict(), (2, 9, 128, 128, 128), lambda B: dict(a=U(B, 0.1, 1), b=U(B, 0.1, 1), c=U(B, 0.1, 1))),
     ("SwiftHohenberg3D B=2", "SwiftHohenberg3DPDELoss", dict(), (2, 9, 64, 64, 64), lambda B: {}),
 ]
