@@ -255,15 +255,18 @@ def main(argv=None):
             torch.cuda.synchronize()
     graph = graphs[0] if graphs else None
     # an eager probe step costs more than a replayed one (the host cannot keep up), so only every 10th step is one
-    probe = max(2, min(10, args.steps // 3)) if graph is not None else 1
-    if graph is not None and n_sets > 1 and probe % n_sets == 0:
+    probe = max(2, min(10, args.steps // 3))
+    if n_sets > 1 and probe % n_sets == 0:
         probe += 1                       # the probes visit every input set in turn
     n_probe = (args.steps + probe - 1) // probe
     pool = lambda n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n + 2)]
     bwd_events, fwd_events = [], []
 
     def step(i):
-        if graph is not None and i % probe != probe - 1:
+        if i % probe != probe - 1:
+            if graph is None:      # --no-graph: an ordinary eager step through the C++ operator
+                buf, names = loss_step(i % n_sets)
+                return pdist.reduce_packed_async(names, buf, force=distributed)
             j = i % len(graphs)
             graphs[j].replay()
             return pdist.reduce_packed_async(keys, g_bufs[j], force=distributed)
@@ -328,7 +331,7 @@ def main(argv=None):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank,
-                       "launch": f"hip-graph replay, every {probe}th step eager with kernel events" if graph is not None else "eager",
+                       "launch": f"hip-graph replay, every {probe}th step eager with kernel events" if graph is not None else f"eager (C++ operator), every {probe}th step with kernel events",
                        "backward_mode": args.mode, "input_sets": n_sets},
             "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step; HIP events recorded by "
                                                      "the library on the launch stream right before and after that launch" +

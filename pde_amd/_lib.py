@@ -110,6 +110,29 @@ def lib():
     return _lib
 
 
+TORCH_LIB_PATH = os.path.join(_HERE, "libpde_amd_torch.so")
+_torch_op = None
+
+
+def torch_op():
+    """The C++ operator pde_amd::residual_losses (autograd node in C++, bound to the loaded kernel library); raises
+    when the operator library has not been built."""
+    global _torch_op
+    if _torch_op is None:
+        lib()
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise RuntimeError(
+                f"pde_amd: {TORCH_LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'`, "
+                "or set PDE_AMD_HOST=ctypes to drive the kernels from the Python autograd function instead.")
+        torch.ops.load_library(TORCH_LIB_PATH)
+        binder = C.CDLL(TORCH_LIB_PATH)
+        binder.pde_amd_torch_bind.restype, binder.pde_amd_torch_bind.argtypes = C.c_int, [C.c_char_p]
+        if binder.pde_amd_torch_bind(LIB_PATH.encode()) != 0:
+            raise RuntimeError(f"pde_amd: could not bind {LIB_PATH} into the torch operator library")
+        _torch_op = torch.ops.pde_amd.residual_losses.default
+    return _torch_op
+
+
 def check(status: int, what: str):
     if status != 0:
         msg = lib().pde_amd_status_string(status).decode()

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -34,6 +35,15 @@ class StencilProblem:
         if key not in cache:
             cache[key] = self._c_struct(shape)
         return cache[key]
+
+    def op_args(self):
+        """(pde id, constants, lo, hi, equations, t_lo, t_hi) as the C++ operator takes them"""
+        a = self.__dict__.get("_op_args")
+        if a is None:
+            s = SPECS[self.spec]
+            a = self.__dict__["_op_args"] = (PDE_IDS[self.spec], [float(v) for v in self.consts], [int(v) for v in self.lo],
+                                             [int(v) for v in self.hi], len(s.eqs), s.tlo, s.thi)
+        return a
 
     def _c_struct(self, shape: Sequence[int]) -> "_lib.Problem":
         s = SPECS[self.spec]
@@ -194,6 +204,12 @@ class HipBackend:
 
 
 _BACKEND = HipBackend()
+# Host path of residual_losses on the HIP backend: "op" = the C++ operator of libpde_amd_torch.so (default),
+# "ctypes" = the Python autograd function below over the ctypes binding (also used while launches are being timed)
+_HOST = os.environ.get("PDE_AMD_HOST", "op")
+if _HOST not in ("op", "ctypes"):
+    raise ValueError(f"PDE_AMD_HOST must be 'op' or 'ctypes', got {_HOST!r}")
+_MODES = {"recompute": 0, "stored": 1, "fused": 2}
 
 
 def set_backend(b):
@@ -257,27 +273,34 @@ class _ResidualLosses(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+def _f32c(t, device):
+    """fp32, contiguous, on `device`; the tensor itself when it already is (the usual case, and the cheap one)"""
+    if t.dtype is not torch.float32 or t.device != device:
+        t = t.to(device=device, dtype=torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _prepare(prob, fields, weights, sparams, aux):
     """Shape checks and fp32-contiguous copies shared by the entry points below."""
     s = SPECS[prob.spec]
     if len(fields) != len(s.fields) or len(sparams) != len(s.sparams) or len(aux) != len(s.aux):
         raise ValueError(f"{prob.spec}: expected {len(s.fields)} fields, {len(s.sparams)} per-sample parameters, {len(s.aux)} aux fields")
-    shape = fields[0].shape
+    f0 = fields[0]
+    shape, dev = f0.shape, f0.device
     fs = []
     for f in fields:
         if f.shape != shape:
             raise ValueError(f"{prob.spec}: all fields must share one shape, got {tuple(f.shape)} vs {tuple(shape)}")
-        fs.append(f.to(torch.float32).contiguous())
-    sp = [p.to(device=fs[0].device, dtype=torch.float32).contiguous() for p in sparams]
-    ax = [x.to(device=fs[0].device, dtype=torch.float32).contiguous() for x in aux]
+        fs.append(_f32c(f, f.device))
+    sp = [_f32c(p, dev) for p in sparams]
+    ax = [_f32c(x, dev) for x in aux]
     for p in sp:
-        if p.shape != (shape[0],):
+        if p.dim() != 1 or p.shape[0] != shape[0]:
             raise ValueError(f"{prob.spec}: per-sample parameters must have shape [{shape[0]}], got {tuple(p.shape)}")
     for x in ax:
-        if tuple(x.shape) != (shape[0],) + tuple(shape[2:]):
+        if x.shape[0] != shape[0] or x.shape[1:] != shape[2:]:
             raise ValueError(f"{prob.spec}: auxiliary fields must be [B, *spatial], got {tuple(x.shape)}")
-    w = weights.to(device=fs[0].device, dtype=torch.float32).contiguous()
-    return fs, sp, ax, w
+    return fs, sp, ax, _f32c(weights, dev)
 
 
 @torch.no_grad()
@@ -301,6 +324,18 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
     gradient of assumed * total in one pass at forward time when the fields need gradients (`assumed` is a device
     scalar); backward hands the gradient out, rescaled on the device if the upstream value differs.
     """
+    be = _BACKEND
+    if type(be) is HipBackend and _HOST == "op" and be.backward_events is None and be.forward_events is None:
+        # the C++ operator: same kernels, same results; checks, conversions and the autograd node in C++
+        assumed = None
+        if type(mode) is tuple:
+            mode, assumed = mode
+        if mode == "auto" or mode == "fused":
+            can = be.can_recompute(prob.spec)
+            if mode == "auto" or not can:
+                mode = "recompute" if mode == "auto" and can else "stored"
+        out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed)
+        return out[:-1], out[-1]
     fs, sp, ax, w = _prepare(prob, fields, weights, sparams, aux)
     if not torch.is_grad_enabled():      # inside Function.forward the grad mode is always off, so it is passed in
         mode = ("nograd", mode)

@@ -60,8 +60,13 @@ class StencilPDELoss(nn.Module):
 
     # -- helpers ----------------------------------------------------------------------------------
     def _problem(self, spatial) -> StencilProblem:
-        key = ("problem", tuple(spatial), tuple(sorted((k, v if isinstance(v, (int, float, str, bool)) else repr(v)) for k, v in self._params().items())))
-        hit = self._wt_cache.get(key)
+        vals = tuple(self._params().values())      # the geometry attributes are public and mutable: part of the key
+        try:
+            key = ("problem", *spatial, vals)
+            hit = self._wt_cache.get(key)
+        except TypeError:                          # an unhashable parameter value
+            key = ("problem", *spatial, repr(vals))
+            hit = self._wt_cache.get(key)
         if hit is None:
             hit = self._wt_cache[key] = self._build_problem(spatial)
         return hit
@@ -129,9 +134,10 @@ class StencilPDELoss(nn.Module):
         return out
 
     def _scale_state(self) -> tuple:
-        bufs = tuple((n, b._version, b.data_ptr()) for n, b in self.named_buffers(recurse=False) if n.startswith("scales_t_"))
+        bufs = tuple((n, b._version, b.data_ptr()) for n, b in self._buffers.items() if b is not None and n.startswith("scales_t_"))
         flag = bool(getattr(self, self.PER_T_FLAG, False))
-        return (tuple((k, float(v)) for k, v in self.eq_scales.items()), tuple((k, float(v)) for k, v in self.eq_weights.items()), flag, bufs)
+        return (tuple(self.eq_scales), tuple(map(float, self.eq_scales.values())), tuple(self.eq_weights),
+                tuple(map(float, self.eq_weights.values())), flag, bufs)
 
     def _fixed_scale(self, eq: str) -> float:
         return float(self.eq_scales[self.SCALE_KEYS.get(eq, eq)])
@@ -140,6 +146,8 @@ class StencilPDELoss(nn.Module):
         if value is None:
             value = default
         if torch.is_tensor(value):
+            if value.dtype is torch.float32 and value.dim() == 1 and value.shape[0] == B and value.device == ref.device:
+                return value
             v = value.to(device=ref.device, dtype=torch.float32).reshape(-1)
             return v.expand(B) if v.numel() == 1 else v
         return torch.full((B,), float(value), dtype=torch.float32, device=ref.device)

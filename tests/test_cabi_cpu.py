@@ -61,3 +61,15 @@ def test_argument_validation_without_a_gpu():
     p = _lib.Problem()
     p.pde_id = 999
     assert l.pde_amd_residual_workspace_bytes(C.byref(p)) == 0
+
+
+def test_torch_operator_library_loads_and_rejects_cpu_tensors():
+    """The C++ operator library registers pde_amd::residual_losses and binds the kernel library; without a HIP tensor
+    it refuses to compute (no CPU path behind it either)."""
+    import pytest
+    import torch
+    from pde_amd import _lib
+    op = _lib.torch_op()
+    assert "Tensor[] fields" in str(op._schema) and str(op._schema).endswith("-> Tensor[]")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        op([torch.zeros(1, 3, 8)], [], [], torch.zeros(1, 2), 0, [1.0], [0, 0, 0], [0, 0, 0], 1, 0, 1, 0, None)

@@ -179,9 +179,10 @@ def test_no_grad_and_partial_requires_grad():
     from pde_amd import functional as PF
     be = PF.get_backend()
     calls = []
-    orig_fb, orig_f = be.forward_backward, be.forward
+    orig_fb, orig_f, orig_host = be.forward_backward, be.forward, PF._HOST
     be.forward_backward = lambda *a, **k: calls.append("fb") or orig_fb(*a, **k)
     be.forward = lambda prob, fields, aux, sp, w, store: calls.append(("f", store)) or orig_f(prob, fields, aux, sp, w, store)
+    PF._HOST = "ctypes"      # the Python autograd function is the one that goes through the backend object
     try:
         for mode in ("fused", "stored"):
             mod.backward_mode = mode
@@ -189,8 +190,65 @@ def test_no_grad_and_partial_requires_grad():
                 t2, _ = mod(u, v, p, nu=torch.tensor([0.02, 0.05], device=dev))
             assert torch.allclose(t0, t2)
     finally:
-        be.forward_backward, be.forward = orig_fb, orig_f
+        be.forward_backward, be.forward, PF._HOST = orig_fb, orig_f, orig_host
     assert calls == [("f", False), ("f", False)]
+    # the C++ operator under no_grad: no autograd node, and no residuals or gradients allocated
+    for mode in ("fused", "stored"):
+        mod.backward_mode = mode
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated(dev)
+        with torch.no_grad():
+            t3, _ = mod(u, v, p, nu=torch.tensor([0.02, 0.05], device=dev))
+        assert t3.grad_fn is None and torch.allclose(t0, t3)
+        assert torch.cuda.memory_allocated(dev) - before < u.numel() * 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["recompute", "stored", "fused"])
+def test_cpp_operator_matches_python_function(mode):
+    """Both host paths drive the same kernels: loss, per-equation losses, per-sample sums and gradients are bit-identical,
+    also with an upstream factor, a per-equation loss in the objective and a gradient w.r.t. the per-sample sums."""
+    from pde_amd import functional as PF
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    base = [torch.randn(3, 6, 24, 40, generator=g).to(dev) for _ in range(3)]
+    nu = torch.tensor([0.02, 0.05, 0.03], device=dev)
+    results = {}
+    orig = PF._HOST
+    try:
+        for host in ("op", "ctypes"):
+            PF._HOST = host
+            for objective in ("total", "mixed"):
+                fields = [b.clone().requires_grad_(i != 1) for i, b in enumerate(base)]
+                mod = PL.TaylorGreen2DPDELoss(nx=40, ny=24, eq_scales={"continuity": 0.5, "x_momentum": 2.0, "y_momentum": 3.0}).to(dev)
+                mod.backward_mode, mod.upstream_hint = mode, 0.1
+                total, losses = mod(*fields, nu=nu)
+                obj = 0.1 * total if objective == "total" else 0.3 * total + 2.0 * losses["x_momentum"] + losses["continuity"]
+                obj.backward()
+                results[(host, objective)] = (total.detach().clone(), [losses[k].detach().clone() for k in mod.EQS],
+                                              mod.last_per_sample.clone(), fields[0].grad.clone(), fields[2].grad.clone())
+                assert fields[1].grad is None
+    finally:
+        PF._HOST = orig
+    # a gradient w.r.t. the per-sample sums (what a sample-weighted objective sends back)
+    prob = mod._problem([24, 40])
+    wt = torch.rand(3, 4, device=dev)
+    coef = torch.tensor([[1.0, 0.5, 0.0], [2.0, 0.0, 1.0], [0.0, 3.0, 1.5]], dtype=torch.float64, device=dev)
+    sums_grads = {}
+    try:
+        for host in ("op", "ctypes"):
+            PF._HOST = host
+            fields = [b.clone().requires_grad_(True) for b in base]
+            totals, sums = PF.residual_losses(prob, fields, wt, [nu], (), mode=mode if mode != "fused" else ("fused", torch.ones((), device=dev)))
+            ((sums * coef).sum().float() + totals[1]).backward()
+            sums_grads[host] = [f.grad.clone() for f in fields]
+    finally:
+        PF._HOST = orig
+    assert all(torch.equal(x, y) for x, y in zip(sums_grads["op"], sums_grads["ctypes"]))
+    for objective in ("total", "mixed"):
+        a, b = results[("op", objective)], results[("ctypes", objective)]
+        assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
 def test_cpu_tensors_are_rejected():
