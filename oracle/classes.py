@@ -55,8 +55,17 @@ class _Cls:
     def fixed_scale(self, eq):
         return float(self.scales[self.scale_key.get(eq, eq)])
 
-    def finish(self, residuals, t_offset=None):
+    def finish(self, residuals, t_offset=None, reduction="mean"):
         out = {}
+        if reduction != "mean":      # fixed scales only, e.g. :286-294
+            for R, eq in zip(residuals, self.eqs):
+                w = float(self.weights[self.scale_key.get(eq, eq)])
+                sq = torch.sum(R ** 2) if reduction == "sum" else R ** 2
+                out[eq] = w * sq / (self.fixed_scale(eq) ** 2)
+            total = sum(out.values())
+            if self.total_key:
+                out["total"] = total
+            return total, out
         for R, eq in zip(residuals, self.eqs):
             w = float(self.weights[self.scale_key.get(eq, eq)])
             if eq in self.guarded and not (w > 0):
@@ -189,7 +198,7 @@ _mk("WaveGaussPDELoss", ("wave",), dict(nx=128, ny=128, Lx=1.0, Ly=1.0, dt=1 / 1
 def _gs(s, A, B, reduction="mean", laplacian="fft"):
     k = s.kw
     fn = O.residuals_gray_scott_fft if laplacian == "fft" else O.residuals_gray_scott_fd
-    return s.finish(fn(A, B, **{n: k[n] for n in ("dx", "dy", "dt", "F", "k", "D_A", "D_B")}))
+    return s.finish(fn(A, B, **{n: k[n] for n in ("dx", "dy", "dt", "F", "k", "D_A", "D_B")}), reduction=reduction)
 
 
 _mk("GrayScottPDELoss", ("A_equation", "B_equation"),
@@ -237,6 +246,25 @@ _mk("TaylorGreenPDELoss", ("continuity", "x_momentum", "y_momentum"),
     lambda s, u, v, p, nu=None: s.finish(O.residuals_tg2d(u, v, p, s.kw["nu"] if nu is None else nu, dx=s.kw["Lx"] / s.kw["nx"],
                                                           dy=s.kw["Ly"] / s.kw["ny"], dt=s.kw["dt"])),
     guarded=("x_momentum", "y_momentum"))
+
+
+def _batched(*fs):
+    return tuple(f.unsqueeze(0) if f.dim() == 3 else f for f in fs)
+
+
+# the spectral legacy classes :28-146, :309-393 (a 3-D input is one sample)
+_mk("ActiveMatterPDELoss", ("continuity", "advection"), dict(nx=256, ny=256, dx=10.0 / 256, dy=10.0 / 256, dt=1.0),
+    lambda s, c, u, v, reduction="mean": s.finish(O.residuals_active_matter_fft(*_batched(c, u, v), dx=s.kw["dx"], dy=s.kw["dy"], dt=s.kw["dt"]),
+                                                  reduction=reduction), total_key=True)
+_mk("ViscoelasticContinuityLoss", ("continuity",), dict(nx=512, ny=512, dx=TWO_PI / 512, dy=2.0 / 512),
+    lambda s, u, v, reduction="mean": s.finish(O.residuals_viscoelastic_cont(*_batched(u, v), dx=s.kw["dx"], dy=s.kw["dy"]), reduction=reduction),
+    total_key=True)
+
+
+def flow_mixing_pde_loss_v2(pred, left, right, bottom, top, vtmax, dt=1 / 999, Lx=1.0, Ly=1.0):
+    """eval/pde_loss_flow_v2.py:179-243"""
+    ut, adv, res = O.flow_mixing_v2(pred, left, right, bottom, top, vtmax=vtmax, dt=dt, Lx=Lx, Ly=Ly)
+    return torch.mean(res ** 2), torch.mean(ut ** 2), torch.mean(adv ** 2), res
 
 
 def build(cls_name: str, **kwargs):

@@ -9,8 +9,8 @@ from .losses import (  # noqa: F401
     APEBenchBurgers2DPDELoss, NSPwCPDELoss, KP2DPDELoss, ShearFlowPDELossNPINN, Burgers2DCHPDELoss,
     ActiveMatterNPINNPDELoss, RayleighBenardFullPDELoss, TurbulentRadiativePDELoss, WaveGaussPDELoss,
     GrayScottPDELoss, Advection3DPDELoss, APEBenchBurgers3DPDELoss, SwiftHohenberg3DPDELoss, Heat3DPDELoss,
-    TaylorGreenPDELoss, TaylorGreen3DPDELoss, NSIncomPDELoss,
-    burgers_pde_loss, burgers_pde_loss_upwind,
+    TaylorGreenPDELoss, TaylorGreen3DPDELoss, NSIncomPDELoss, ActiveMatterPDELoss, ViscoelasticContinuityLoss,
+    burgers_pde_loss, burgers_pde_loss_upwind, flow_mixing_pde_loss_v2, compute_flow_coefficients, pad_with_boundaries_1x,
 )
 
 from .boundary import (  # noqa: F401

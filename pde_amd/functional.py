@@ -273,6 +273,55 @@ class _ResidualLosses(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+class _ResidualsInGraph(torch.autograd.Function):
+    """outputs: totals[0..n_eqs] as 0-dim tensors, sums[B, n_eqs], then the residual fields R_k [B, T_res, *spatial]
+    (zero outside the lattice), all differentiable w.r.t. the fields.  One forward launch (the residual-storing one).
+    backward: the stored-residual adjoint for the upstream of totals and sums; for an upstream g_k of a residual field the
+    same kernel with g_k in the place of the stored residuals and weights 1/2, which makes it the plain product J^T g."""
+
+    @staticmethod
+    def forward(ctx, prob, aux, sparams, weights, *fields):
+        totals, sums, resid = _BACKEND.forward(prob, fields, aux, sparams, weights, True)
+        ctx.prob, ctx.aux, ctx.sparams, ctx.weights, ctx.nf = prob, aux, sparams, weights, len(fields)
+        ctx.save_for_backward(*fields, *resid)
+        ctx.set_materialize_grads(False)
+        return (*totals.unbind(0), sums, *resid)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        saved = ctx.saved_tensors
+        fields, resid = saved[:ctx.nf], saved[ctx.nf:]
+        ne = len(resid)
+        gtot, gsums, gres = gouts[:ne + 1], gouts[ne + 1], gouts[ne + 2:]
+        ups = [g.to(torch.float32).contiguous() if g is not None else None for g in gtot]
+        gs = gsums.to(torch.float64).contiguous() if gsums is not None else None
+        grads = None
+        if gs is not None or any(u is not None for u in ups):
+            grads = _BACKEND.backward(ctx.prob, fields, ctx.aux, ctx.sparams, ctx.weights,
+                                      ups if any(u is not None for u in ups) else None, gs, list(resid))
+        if any(g is not None for g in gres):
+            f0 = fields[0]
+            g = [x.to(torch.float32).contiguous() if x is not None else torch.zeros_like(resid[0]) for x in gres]
+            half = torch.full_like(ctx.weights, 0.5)
+            one = torch.ones((), dtype=torch.float32, device=f0.device)
+            extra = _BACKEND.backward(ctx.prob, fields, ctx.aux, ctx.sparams, half, [None] * ne + [one], None, g)
+            grads = extra if grads is None else [a.add_(b) for a, b in zip(grads, extra)]
+        if grads is None:
+            return (None,) * (4 + ctx.nf)
+        out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:])]
+        return (None, None, None, None, *out)
+
+
+def residual_losses_and_fields(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
+                               sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = ()):
+    """residual_losses plus the residual fields themselves, in the autograd graph like the reference's
+    (e.g. finetune/pde_loss.py:216 returns them next to the losses): (totals, sums, [R_k [B, T_res, *spatial]])."""
+    fs, sp, ax, w = _prepare(prob, fields, weights, sparams, aux)
+    ne = len(SPECS[prob.spec].eqs)
+    out = _ResidualsInGraph.apply(prob, tuple(ax), tuple(sp), w, *fs)
+    return list(out[:ne + 1]), out[ne + 1], list(out[ne + 2:])
+
+
 def _f32c(t, device):
     """fp32, contiguous, on `device`; the tensor itself when it already is (the usual case, and the cheap one)"""
     if t.dtype is not torch.float32 or t.device != device:

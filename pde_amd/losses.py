@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functional import StencilProblem, residual_fields, residual_losses
+from .functional import StencilProblem, residual_fields, residual_losses, residual_losses_and_fields
 from .stencil.specs import SPECS
 
 Tensor = torch.Tensor
@@ -153,7 +153,9 @@ class StencilPDELoss(nn.Module):
         return torch.full((B,), float(value), dtype=torch.float32, device=ref.device)
 
     def _evaluate(self, fields: Sequence[Tensor], sparams: Sequence[Tensor] = (), aux: Sequence[Tensor] = (),
-                  t_offset: Optional[Tensor] = None):
+                  t_offset: Optional[Tensor] = None, reduction: str = "mean"):
+        if reduction != "mean":
+            return self._evaluate_unreduced(fields, sparams, aux, reduction)
         spec = SPECS[self.SPEC]
         f0 = fields[0]
         if f0.dim() != 2 + spec.ndim:
@@ -186,6 +188,37 @@ class StencilPDELoss(nn.Module):
                 losses[eq] = totals[k]
         # the kernel's fp32 left-to-right sum is the reference's sum(losses.values()) when nothing was skipped
         total = totals[-1] if all_kept else sum(losses.values())
+        if self.TOTAL_KEY:
+            losses["total"] = total
+        return total, losses
+
+    def _evaluate_unreduced(self, fields, sparams, aux, reduction: str):
+        """reduction 'sum' or 'none' with the fixed scales, as the reference's classes that take the argument do
+        (finetune/pde_loss_verified.py:286-294): w_k * sum(R_k^2) / s_k^2, or the fields w_k * R_k^2 / s_k^2 themselves
+        (on the residual lattice, in the autograd graph) and their sum as the total."""
+        if reduction not in ("sum", "none"):
+            raise ValueError(f"reduction must be 'mean', 'sum' or 'none', got {reduction!r}")
+        spec = SPECS[self.SPEC]
+        f0 = fields[0]
+        if f0.dim() != 2 + spec.ndim:
+            raise ValueError(f"{type(self).__name__}: fields must be [B, T, {spec.ndim} spatial dims], got {tuple(f0.shape)}")
+        spatial = list(f0.shape[2:])
+        prob = self._problem(spatial)
+        T_res = f0.shape[1] - spec.tlo - spec.thi
+        coef = [float(self.eq_weights[self.SCALE_KEYS.get(eq, eq)]) / self._fixed_scale(eq) ** 2 for eq in self.EQS]
+        wt = torch.tensor(coef, dtype=torch.float32, device=f0.device)[:, None].expand(len(coef), max(T_res, 0)).contiguous()
+        losses: Dict[str, Tensor] = {}
+        if reduction == "sum":
+            totals, _ = residual_losses(prob, fields, wt, sparams, aux, mode=self.backward_mode if self.backward_mode != "fused" else "auto")
+            losses.update(zip(self.EQS, totals[:-1]))
+            total = totals[-1]
+        else:
+            _, _, resid = residual_losses_and_fields(prob, fields, wt, sparams, aux)
+            full = [1] * (3 - spec.ndim) + spatial
+            crop = (slice(None), slice(None)) + tuple(slice(prob.lo[a], full[a] - prob.hi[a]) for a in range(3 - spec.ndim, 3))
+            for eq, c, r in zip(self.EQS, coef, resid):
+                losses[eq] = c * r[crop] ** 2
+            total = sum(losses.values())
         if self.TOTAL_KEY:
             losses["total"] = total
         return total, losses
@@ -707,14 +740,87 @@ class GrayScottPDELoss(StencilPDELoss):
         return torch.fft.irfft2(negK2 * torch.fft.rfft2(f), s=f.shape[-2:])
 
     def forward(self, A: Tensor, B: Tensor, reduction: str = "mean"):
-        if reduction != "mean":
-            raise NotImplementedError("only reduction='mean' runs on the fused kernels")
         if A.dim() == 3:
             A, B = A.unsqueeze(0), B.unsqueeze(0)
         if self.laplacian == "fd4":
-            return self._evaluate([A, B])
+            return self._evaluate([A, B], reduction=reduction)
         lap = self.fft_laplacian(torch.stack([A.to(torch.float32), B.to(torch.float32)]))      # both fields in one batched transform
-        return self._evaluate([A, B, lap[0], lap[1]])
+        return self._evaluate([A, B, lap[0], lap[1]], reduction=reduction)
+
+
+def _half_wavenumbers(n_full: int, d_full: float, n_half: int, d_half: float):
+    """(KX, KY) of a real 2-D transform over (dim -2, dim -1): all of axis -2, the non-negative half of axis -1, times i
+    left to the caller.  The Nyquist rows are zeroed: for a first derivative the reference's `ifft2(1j * K * fft2(f)).real`
+    drops exactly that part (it is not conjugate-symmetric), and a half-spectrum inverse would keep half of it."""
+    kx = torch.fft.fftfreq(n_full, d=d_full) * 2 * np.pi
+    ky = torch.fft.rfftfreq(n_half, d=d_half) * 2 * np.pi
+    if n_full % 2 == 0:
+        kx[n_full // 2] = 0.0
+    if n_half % 2 == 0:
+        ky[-1] = 0.0
+    return torch.meshgrid(kx, ky, indexing="ij")
+
+
+class ActiveMatterPDELoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:28-146 — the spectral (doubly periodic) active-matter class: div(u) = 0 and
+    dc/dt + u . grad c = 0 with a forward time difference; forward(c, u, v, reduction).  The four spectral derivatives
+    are rocFFT transforms (torch.fft, half spectrum); the residuals, their reduction and the adjoint of the pointwise part
+    run in the stencil kernels, autograd carries the gradient back through the transforms."""
+    SPEC, EQS, TOTAL_KEY = "active_matter_fft", ("continuity", "advection"), True
+
+    def __init__(self, nx: int = 256, ny: int = 256, dx: float = 10.0 / 256, dy: float = 10.0 / 256, dt: float = 1.0):
+        super().__init__()
+        self.nx, self.ny, self.dx, self.dy, self.dt = nx, ny, dx, dy, dt
+        self._init_common({"continuity": 1.0, "advection": 1.0}, None, None, None, per_t_supported=False)
+        KX, KY = torch.meshgrid(torch.fft.fftfreq(nx, d=dx) * 2 * np.pi, torch.fft.fftfreq(ny, d=dy) * 2 * np.pi, indexing="ij")
+        self.register_buffer("KX", KX)      # the reference's buffers (:54-61); the transforms below use their half-spectrum forms
+        self.register_buffer("KY", KY)
+
+    def _params(self):
+        return dict(dt=self.dt)
+
+    def _derivatives(self, f: Tensor):
+        """(df/dx, df/dy) over the last two axes, one forward transform (:63-77)"""
+        kxh, kyh = self._buf("Kh", lambda: torch.stack(_half_wavenumbers(self.nx, self.dx, self.ny, self.dy)), f.device)
+        fh = torch.fft.rfft2(f)
+        return torch.fft.irfft2(1j * kxh * fh, s=f.shape[-2:]), torch.fft.irfft2(1j * kyh * fh, s=f.shape[-2:])
+
+    def forward(self, c: Tensor, u: Tensor, v: Tensor, reduction: str = "mean"):
+        if c.dim() == 3:
+            c, u, v = c.unsqueeze(0), u.unsqueeze(0), v.unsqueeze(0)
+        c, u, v = c.to(torch.float32), u.to(torch.float32), v.to(torch.float32)
+        cx, cy = self._derivatives(c)
+        ux, _ = self._derivatives(u)
+        _, vy = self._derivatives(v)
+        return self._evaluate([c, u * cx + v * cy, ux + vy], reduction=reduction)
+
+
+class ViscoelasticContinuityLoss(StencilPDELoss):
+    """finetune/pde_loss_verified.py:309-393 — continuity only: spectral du/dx along the periodic x (dim -2), central
+    dv/dy on the interior of the wall-bounded y (dim -1), every frame; forward(u, v, reduction)."""
+    SPEC, EQS, TOTAL_KEY = "viscoelastic_cont", ("continuity",), True
+
+    def __init__(self, nx: int = 512, ny: int = 512, dx: float = 2 * np.pi / 512, dy: float = 2.0 / 512):
+        super().__init__()
+        self.nx, self.ny, self.dx, self.dy = nx, ny, dx, dy
+        self._init_common({"continuity": 1.0}, None, None, None, per_t_supported=False)
+        self.register_buffer("kx", (torch.fft.fftfreq(nx, d=dx) * 2 * np.pi).view(nx, 1))      # :341-342
+
+    def _params(self):
+        return dict(dy=self.dy)
+
+    def _lattice(self, spatial):
+        return (0, 0, 1), (0, 0, 1)
+
+    def fft_dx(self, f: Tensor) -> Tensor:
+        """spectral derivative along dim -2 (:344-349); the half-spectrum inverse drops the Nyquist term as `.real` does"""
+        kh = self._buf("kxh", lambda: (torch.fft.rfftfreq(self.nx, d=self.dx) * 2 * np.pi).view(-1, 1), f.device)
+        return torch.fft.irfft(1j * kh * torch.fft.rfft(f, dim=-2), n=f.shape[-2], dim=-2)
+
+    def forward(self, u: Tensor, v: Tensor, reduction: str = "mean"):
+        if u.dim() == 3:
+            u, v = u.unsqueeze(0), v.unsqueeze(0)
+        return self._evaluate([self.fft_dx(u.to(torch.float32)), v], reduction=reduction)
 
 
 # =================================================================================================
@@ -834,9 +940,8 @@ class TaylorGreen3DPDELoss(StencilPDELoss):
 def burgers_pde_loss(pred: Tensor, nu: float, dt: float = 1 / 999, dx: float = 1 / 127, dy: float = 1 / 127):
     """finetune/pde_loss.py:87-216 — returns (total, loss_u, loss_v, residual_u, residual_v).
 
-    pred is channel-last [B, T, H, W, 2]; residuals are [B, T-1, H-2, W-2] (detached: they are diagnostics).
+    pred is channel-last [B, T, H, W, 2]; residuals are [B, T-1, H-2, W-2], differentiable like the losses.
     """
-    from .functional import get_backend  # late: tests may swap it
     B, T, H, W, C2 = pred.shape
     assert T >= 2, "T must be at least 2"
     assert H >= 4 and W >= 4, "H, W must be at least 4"
@@ -846,13 +951,64 @@ def burgers_pde_loss(pred: Tensor, nu: float, dt: float = 1 / 999, dx: float = 1
     prob = StencilProblem("burgers2d_ghost", [fn(p) for _, fn in spec.consts], (0, 1, 1), (0, 1, 1))
     n = B * (T - 1) * (H - 2) * (W - 2)
     wt = torch.full((2, T - 1), 1.0 / n, dtype=torch.float32, device=pred.device)
-    totals, _ = residual_losses(prob, [u, v], wt, mode="stored")
-    loss_u, loss_v = totals[0], totals[1]
-    with torch.no_grad():
-        fs = [u.detach().float().contiguous(), v.detach().float().contiguous()]
-        _, _, resid = get_backend().forward(prob, fs, (), (), wt, True)
+    totals, _, resid = residual_losses_and_fields(prob, [u, v], wt)      # one forward launch; the residuals stay in the graph (:216)
     ru, rv = (r[:, :, 1:H - 1, 1:W - 1] for r in resid)
-    return totals[2], loss_u, loss_v, ru, rv
+    return totals[2], totals[0], totals[1], ru, rv
 
 
 burgers_pde_loss_upwind = burgers_pde_loss
+
+
+# =================================================================================================
+# flow mixing, central differences with ghost cells (eval/pde_loss_flow_v2.py)
+# =================================================================================================
+def compute_flow_coefficients(H: int, W: int, vtmax: float, device, dtype=torch.float32):
+    """eval/pde_loss_flow_v2.py:18-54 — the advection coefficients a = -omega y, b = omega x on the interior grid [H, W]."""
+    x = torch.linspace(1 / 256, 255 / 256, W, device=device, dtype=dtype)
+    y = torch.linspace(1 / 256, 255 / 256, H, device=device, dtype=dtype)
+    Y, X = torch.meshgrid(y, x, indexing="ij")
+    r = torch.sqrt(X ** 2 + Y ** 2).clamp(min=1e-10)
+    rc = r.clamp(max=20.0)
+    omega = (1.0 / torch.cosh(rc)) ** 2 * torch.tanh(rc) / (r * vtmax + 1e-10)
+    return -omega * Y, omega * X
+
+
+def pad_with_boundaries_1x(interior: Tensor, boundary_left: Tensor, boundary_right: Tensor, boundary_bottom: Tensor,
+                           boundary_top: Tensor) -> Tensor:
+    """eval/pde_loss_flow_v2.py:57-111 — one layer of linearly extrapolated ghost cells (2 boundary - first interior
+    value), corners the mean of their two neighbours' ghosts: [B, T, H, W] -> [B, T, H+2, W+2], differentiable."""
+    gl = 2 * boundary_left.squeeze(-1) - interior[..., 0]
+    gr = 2 * boundary_right.squeeze(-1) - interior[..., -1]
+    gb = 2 * boundary_bottom.squeeze(-2) - interior[..., 0, :]
+    gt = 2 * boundary_top.squeeze(-2) - interior[..., -1, :]
+    mid = torch.cat([gl.unsqueeze(-1), interior, gr.unsqueeze(-1)], dim=-1)
+    bottom = torch.cat([(gl[..., :1] + gb[..., :1]) / 2, gb, (gr[..., :1] + gb[..., -1:]) / 2], dim=-1)
+    top = torch.cat([(gl[..., -1:] + gt[..., :1]) / 2, gt, (gr[..., -1:] + gt[..., -1:]) / 2], dim=-1)
+    return torch.cat([bottom.unsqueeze(-2), mid, top.unsqueeze(-2)], dim=-2)
+
+
+_flow_coef_cache = {}
+
+
+def flow_mixing_pde_loss_v2(pred: Tensor, boundary_left: Tensor, boundary_right: Tensor, boundary_bottom: Tensor,
+                            boundary_top: Tensor, vtmax: float, dt: float = 1 / 999, Lx: float = 1.0, Ly: float = 1.0):
+    """eval/pde_loss_flow_v2.py:179-243 — returns (pde_loss, loss_time, loss_advection, residual [B, T-1, H, W]).
+
+    pred [B, T, H, W, 1]; the ghost layer is assembled with tensor ops (a few strips), the three mean squares and the
+    residual field come from one stencil launch on the padded field, and everything stays differentiable."""
+    B, T, H, W, _ = pred.shape
+    u = pred[..., 0].to(torch.float32)
+    padded = pad_with_boundaries_1x(u, boundary_left[..., 0].to(torch.float32), boundary_right[..., 0].to(torch.float32),
+                                    boundary_bottom[..., 0].to(torch.float32), boundary_top[..., 0].to(torch.float32))
+    key = (H, W, float(vtmax), B, str(pred.device))
+    coef = _flow_coef_cache.get(key)
+    if coef is None:
+        a, b = compute_flow_coefficients(H, W, vtmax, pred.device)
+        coef = _flow_coef_cache[key] = tuple(torch.nn.functional.pad(x, (1, 1, 1, 1)).expand(B, H + 2, W + 2).contiguous() for x in (a, b))
+    spec = SPECS["flow_mixing_v2"]
+    p = dict(dt=dt, dx=Lx / W, dy=Ly / H)
+    prob = StencilProblem("flow_mixing_v2", [fn(p) for _, fn in spec.consts], (0, 1, 1), (0, 1, 1))
+    n = B * (T - 1) * H * W
+    wt = torch.full((3, T - 1), 1.0 / n, dtype=torch.float32, device=pred.device)
+    totals, _, resid = residual_losses_and_fields(prob, [padded], wt, (), coef)
+    return totals[2], totals[0], totals[1], resid[2][:, :, 1:H + 1, 1:W + 1]

@@ -419,6 +419,35 @@ def _gray_scott_pw():
     return b.done([ra, rb])
 
 
+def _active_matter_fft():
+    # ActiveMatterPDELoss (the spectral, non-n-PINN class) :28-146 — continuity = du/dx + dv/dy, advection =
+    # (c[t+1] - c[t]) / dt + u dc/dx + v dc/dy at frame t; the spectral derivatives come in as fields: `div` is the
+    # divergence, `adv` the transport term (rocFFT through torch.fft and two products); pointwise residual + reduction here
+    b = _B("active_matter_fft", 2, ["c", "adv", "div"], ["continuity", "advection"])
+    c, adv, div = b.F()
+    return b.done([div, (tsh(c, 1) - c) * b.c("inv_dt", _inv("dt")) + adv])
+
+
+def _viscoelastic_cont():
+    # ViscoelasticContinuityLoss :309-393 — R = du/dx (spectral along x = dim -2, supplied as the field `ux`) +
+    # (v[y+1] - v[y-1]) / (2 dy) on the interior of the wall-bounded y axis (dim -1); every frame, no time derivative
+    b = _B("viscoelastic_cont", 2, ["ux", "v"], ["continuity"], periodic=(True, True, False))
+    ux, v = b.F()
+    return b.done([ux + _d1c2(b, v, 2, "dy")])
+
+
+def _flow_mixing_v2():
+    # flow_mixing_pde_loss_v2, eval/pde_loss_flow_v2.py:179-243 on the ghost-padded field [B, T, H+2, W+2] (:57-111):
+    # time = (u[t] - u[t-1]) / dt, advection = a (uE - uW) / (2 dx) + b (uN - uS) / (2 dy) with the coefficient fields
+    # a, b (:18-54), residual = their sum; lattice = the interior; x = dim -1, y = dim -2
+    b = _B("flow_mixing_v2", 2, ["u"], ["time", "advection", "residual"], periodic=(True, False, False), aux_names=["a", "b"])
+    u = b.F()
+    ca, cb = b.A(0), b.A(1)
+    rt = (u - tsh(u, -1)) * b.c("inv_dt", _inv("dt"))
+    ra = ca * _d1c2(b, u, 2, "dx") + cb * _d1c2(b, u, 1, "dy")
+    return b.done([rt, ra, rt + ra])
+
+
 # ---- 3-D periodic family ------------------------------------------------------------------------
 def _advection3d():
     # Advection3DPDELoss :2796-2917 — x,y,z = dims -3,-2,-1; per-sample a,b,c
@@ -512,7 +541,8 @@ def _ns_incom():
 for _f in (_burgers1d, _advection1d, _heat1d, _ape_burgers1d, _ks1d, _kdv1d, _tg2d, _advdiff2d, _anisodiff2d,
            _wave2d, _ape_burgers2d, _nspwc, _kp2d, _shear_flow, _burgers2d_ch, _active_matter,
            _rayleigh_benard, _turbulent_radiative, _wave_gauss, _burgers2d_ghost, _gray_scott_fd,
-           _gray_scott_pw, _advection3d, _ape_burgers3d, _swift_hohenberg3d, _heat3d, _tg3d, _ns_incom):
+           _gray_scott_pw, _advection3d, _ape_burgers3d, _swift_hohenberg3d, _heat3d, _tg3d, _ns_incom,
+           _active_matter_fft, _viscoelastic_cont, _flow_mixing_v2):      # new PDEs go last: ids are part of the C ABI
     _reg(_f())
 
 PDE_IDS = {name: i for i, name in enumerate(SPECS)}

@@ -153,6 +153,8 @@ class InterpBackend:
         s, F, A, SP, C, R, TR = self._residuals(prob, fields, aux, sparams)
         B, T = F[0].shape[:2]
         ne = len(s.eqs)
+        if resid is not None:      # stored mode: whatever the caller passes stands in for the residuals
+            R = [r.detach().cpu().double().numpy().reshape(R[k].shape) for k, r in enumerate(resid)]
         w = weights.detach().cpu().double().numpy()          # [NE, TR]
         u = np.zeros((B, ne))
         if upstream is not None:

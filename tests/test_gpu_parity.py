@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 import pde_amd.losses as PL
 from oracle import classes as OC
-from tests.helpers import GOLDEN, golden_cases, load_case, rel_l2
+from tests.helpers import GOLDEN, backprop, close, golden_cases, load_case, rel_l2
 
 TOL = 1e-5
 
@@ -27,7 +27,7 @@ def _dev():
 def _run(mod, fields, extra):
     fields = [f.clone().requires_grad_(True) for f in fields]
     total, losses = mod(*fields, **extra)
-    total.backward()
+    backprop(total)
     return total, losses, [f.grad for f in fields]
 
 
@@ -39,13 +39,11 @@ def test_golden(name, mode):
     mod = getattr(PL, meta["cls"])(**kwargs).to(dev)
     mod.backward_mode = mode
     total, losses, grads = _run(mod, fields, extra)
-    ref_total = float(z["f64_total"])
-    assert abs(float(total) - ref_total) <= TOL * abs(ref_total)
+    assert close(total, z["f64_total"], TOL)
     ref_keys = sorted(k[9:] for k in z.files if k.startswith("f64_loss_"))
     assert sorted(losses) == ref_keys
     for k in ref_keys:
-        ref = float(z[f"f64_loss_{k}"])
-        assert abs(float(losses[k]) - ref) <= TOL * abs(ref) + 1e-30, k
+        assert close(losses[k], z[f"f64_loss_{k}"], TOL, 1e-30), k
     for n, g in zip(meta["fields"], grads):
         ref = z[f"f64_grad_{n}"]
         got = g.cpu().numpy() if g is not None else np.zeros_like(ref)
@@ -60,8 +58,8 @@ def test_ghost_burgers_golden():
     total, lu, lv, ru, rv = PL.burgers_pde_loss(pred, m["nu"], dt=m["dt"], dx=m["dx"], dy=m["dy"])
     total.backward()
     assert abs(float(total) - float(z["f64_total"])) <= TOL * abs(float(z["f64_total"]))
-    assert rel_l2(ru.cpu().numpy(), z["f64_res_u"]) <= TOL
-    assert rel_l2(rv.cpu().numpy(), z["f64_res_v"]) <= TOL
+    assert ru.requires_grad and rel_l2(ru.detach().cpu().numpy(), z["f64_res_u"]) <= TOL
+    assert rel_l2(rv.detach().cpu().numpy(), z["f64_res_v"]) <= TOL
     assert rel_l2(pred.grad.cpu().numpy(), z["f64_grad_pred"]) <= TOL
 
 
@@ -435,3 +433,37 @@ def test_full_size_heat3d_properties():
     alpha = 0.005 + 0.045 * torch.rand(2, generator=gen, device=dev)
     mod = PL.Heat3DPDELoss().to(dev)
     _full_size_properties(mod, fields, dict(alpha=alpha), (5, 17, 68), modes=("auto", "fused"))
+
+
+def test_flow_mixing_v2_golden():
+    """flow_mixing_pde_loss_v2 against the reference's values (eval/pde_loss_flow_v2.py run on the same inputs): the three
+    losses, the residual field, and the gradients w.r.t. the prediction and all four boundary tensors."""
+    z = np.load(os.path.join(GOLDEN, "flow_v2.npz"))
+    m = json.loads(bytes(z["meta"]).decode())
+    names = ("pred", "left", "right", "bottom", "top")
+    ins = [torch.tensor(z[f"in_{n}"], dtype=torch.float32, device=_dev(), requires_grad=True) for n in names]
+    loss, lt, la, res = PL.flow_mixing_pde_loss_v2(*ins, **m)
+    (loss + 0.5 * lt + 0.25 * la + 0.01 * res.sum()).backward()
+    for n, x in (("loss", loss), ("loss_time", lt), ("loss_adv", la), ("residual", res)):
+        assert close(x, z[f"f64_{n}"], TOL), n
+    for n, x in zip(names, ins):
+        assert rel_l2(x.grad.cpu().numpy(), z[f"f64_grad_{n}"]) <= TOL, n
+
+
+def test_ghost_burgers_residuals_are_in_graph():
+    """The residual fields burgers_pde_loss returns are differentiable (finetune/pde_loss.py:216): objectives built from
+    them, alone or mixed with the losses, against autograd through the fp64 oracle."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    base = torch.randn(2, 4, 9, 12, 2, generator=g)
+    wgt = torch.randn(2, 3, 7, 10, generator=g)
+    objectives = (lambda t, lu, ru, rv, w: (ru * w).sum() + 0.5 * (rv ** 2).mean(),
+                  lambda t, lu, ru, rv, w: 2.0 * t + lu + (rv * w).sum())
+    for use in objectives:
+        pred = base.clone().to(dev).requires_grad_(True)
+        t, lu, lv, ru, rv = PL.burgers_pde_loss(pred, 0.03, dt=0.02, dx=0.11, dy=0.13)
+        use(t, lu, ru, rv, wgt.to(dev)).backward()
+        p64 = base.double().requires_grad_(True)
+        ot, olu, olv, oru, orv = OC.burgers_pde_loss(p64, 0.03, dt=0.02, dx=0.11, dy=0.13)
+        use(ot, olu, oru, orv, wgt.double()).backward()
+        assert rel_l2(pred.grad.cpu().numpy(), p64.grad.numpy()) <= TOL

@@ -13,7 +13,7 @@ import torch
 import pde_amd.losses as PL
 from oracle import classes as OC
 from pde_amd import functional as PF
-from tests.helpers import GOLDEN, golden_cases, load_case, rel_l2
+from tests.helpers import GOLDEN, backprop, close, golden_cases, load_case, rel_l2
 from tests.spec_interp import InterpBackend
 
 
@@ -27,7 +27,7 @@ def interp_backend():
 def _run(mod, fields, extra):
     fields = [f.clone().requires_grad_(True) for f in fields]
     total, losses = mod(*fields, **extra)
-    total.backward()
+    backprop(total)
     return total, losses, [f.grad for f in fields]
 
 
@@ -36,13 +36,11 @@ def test_classes_match_reference_golden(name):
     meta, kwargs, fields, extra, z = load_case(name, torch.float32)
     mod = getattr(PL, meta["cls"])(**kwargs)
     total, losses, grads = _run(mod, fields, extra)
-    ref_total = float(z["f32_total"])
-    assert abs(float(total) - ref_total) <= 2e-5 * abs(ref_total)
+    assert close(total, z["f32_total"], 2e-5)
     ref_keys = sorted(k[9:] for k in z.files if k.startswith("f32_loss_"))
     assert sorted(losses) == ref_keys
     for k in ref_keys:
-        ref = float(z[f"f64_loss_{k}"])
-        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref) + 1e-30, k
+        assert close(losses[k], z[f"f64_loss_{k}"], 2e-5, 1e-30), k
     for n, g in zip(meta["fields"], grads):
         ref = z[f"f64_grad_{n}"]
         got = g.numpy() if g is not None else np.zeros_like(ref)
@@ -58,8 +56,8 @@ def test_classes_match_oracle_tightly(name):
     f64 = [f.double().requires_grad_(True) for f in fields]
     e64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in extra.items()}
     ototal, olosses = OC.build(meta["cls"], **kwargs)(*f64, **e64)
-    ototal.backward()
-    assert abs(float(total) - float(ototal)) <= 3e-6 * abs(float(ototal))
+    backprop(ototal)
+    assert close(total, ototal.detach().numpy(), 3e-6)
     for n, g, f in zip(meta["fields"], grads, f64):
         ref = f.grad.numpy() if f.grad is not None else np.zeros(f.shape)
         got = g.numpy() if g is not None else np.zeros_like(ref)
@@ -75,9 +73,27 @@ def test_ghost_burgers_function():
     assert abs(float(total) - float(z["f64_total"])) <= 2e-5 * abs(float(z["f64_total"]))
     assert abs(float(lu) - float(z["f64_loss_u"])) <= 2e-5 * abs(float(z["f64_loss_u"]))
     assert ru.shape == z["f64_res_u"].shape
-    assert rel_l2(ru.numpy(), z["f64_res_u"]) <= 2e-5
-    assert rel_l2(rv.numpy(), z["f64_res_v"]) <= 2e-5
+    assert ru.requires_grad and rel_l2(ru.detach().numpy(), z["f64_res_u"]) <= 2e-5
+    assert rel_l2(rv.detach().numpy(), z["f64_res_v"]) <= 2e-5
     assert rel_l2(pred.grad.numpy(), z["f64_grad_pred"]) <= 2e-5
+
+
+def test_ghost_burgers_residuals_are_in_graph():
+    """The returned residual fields are differentiable, as the reference's are (finetune/pde_loss.py:216): an objective
+    built from them, alone or mixed with the losses, against autograd through the oracle."""
+    g = torch.Generator().manual_seed(12)
+    base = torch.randn(2, 4, 9, 12, 2, generator=g)
+    wgt = torch.randn(2, 3, 7, 10, generator=g)
+    objectives = (lambda t, lu, ru, rv, w: (ru * w).sum() + 0.5 * (rv ** 2).mean(),
+                  lambda t, lu, ru, rv, w: 2.0 * t + lu + (rv * w).sum())
+    for use in objectives:
+        pred = base.clone().requires_grad_(True)
+        t, lu, lv, ru, rv = PL.burgers_pde_loss(pred, 0.03, dt=0.02, dx=0.11, dy=0.13)
+        use(t, lu, ru, rv, wgt).backward()
+        p64 = base.double().requires_grad_(True)
+        ot, olu, olv, oru, orv = OC.burgers_pde_loss(p64, 0.03, dt=0.02, dx=0.11, dy=0.13)
+        use(ot, olu, oru, orv, wgt.double()).backward()
+        assert rel_l2(pred.grad.numpy(), p64.grad.numpy()) <= 3e-5
 
 
 def test_heat3d_matches_oracle():
@@ -166,3 +182,18 @@ def test_scales_and_weights_changed_after_the_first_call_take_effect():
     ref.per_t_bufs["continuity"] = ref.per_t_bufs["continuity"] * 2.0
     v3 = same()
     assert len({v0, v1, v2, v3}) == 4
+
+
+def test_flow_mixing_v2_golden():
+    """flow_mixing_pde_loss_v2 against the reference's values (eval/pde_loss_flow_v2.py run on the same inputs): the three
+    losses, the residual field, and the gradients w.r.t. the prediction and all four boundary tensors."""
+    z = np.load(os.path.join(GOLDEN, "flow_v2.npz"))
+    m = json.loads(bytes(z["meta"]).decode())
+    names = ("pred", "left", "right", "bottom", "top")
+    ins = [torch.tensor(z[f"in_{n}"], dtype=torch.float32, device="cpu", requires_grad=True) for n in names]
+    loss, lt, la, res = PL.flow_mixing_pde_loss_v2(*ins, **m)
+    (loss + 0.5 * lt + 0.25 * la + 0.01 * res.sum()).backward()
+    for n, x in (("loss", loss), ("loss_time", lt), ("loss_adv", la), ("residual", res)):
+        assert close(x, z[f"f64_{n}"], 2e-5), n
+    for n, x in zip(names, ins):
+        assert rel_l2(x.grad.cpu().numpy(), z[f"f64_grad_{n}"]) <= 2e-5, n

@@ -101,6 +101,15 @@ def cases():
     C["advection3d"] = ("Advection3DPDELoss", dict(dx=0.2, dy=0.3, dz=0.25, dt=0.05), ["u"], S3,
                         dict(a=_uniform(2, -1, 1, 8), b=_uniform(2, -1, 1, 9), c=_uniform(2, -1, 1, 10)))
     C["ape_burgers3d"] = ("APEBenchBurgers3DPDELoss", dict(nx=6, Lx=1.0, dt=1.0, eq_scales={"u_momentum": 0.1}), ["u", "v", "w"], S3, {})
+    # reductions other than the mean (:286-294), and the spectral legacy classes (:28-146, :309-393)
+    C["gray_scott_sum"] = ("GrayScottPDELoss", dict(nx=12, ny=10, dx=0.2, dy=0.2, dt=10.0, eq_scales={"A": 0.5, "B": 2.0}, eq_weights={"A": 1.5, "B": 0.5}),
+                           ["A", "B"], S2, dict(reduction="sum"))
+    C["gray_scott_none"] = ("GrayScottPDELoss", dict(nx=12, ny=10, dx=0.2, dy=0.2, dt=10.0, eq_scales={"A": 0.5, "B": 2.0}),
+                            ["A", "B"], S2, dict(reduction="none"))
+    C["active_matter_fft"] = ("ActiveMatterPDELoss", dict(nx=12, ny=10, dx=0.3, dy=0.25, dt=0.5), ["c", "u", "v"], S2, {})
+    C["active_matter_fft_sum"] = ("ActiveMatterPDELoss", dict(nx=12, ny=10, dx=0.3, dy=0.25, dt=0.5), ["c", "u", "v"], S2, dict(reduction="sum"))
+    C["viscoelastic_cont"] = ("ViscoelasticContinuityLoss", dict(nx=12, ny=10, dx=0.3, dy=0.25), ["u", "v"], S2, {})
+    C["viscoelastic_cont_none"] = ("ViscoelasticContinuityLoss", dict(nx=12, ny=10, dx=0.3, dy=0.25), ["u", "v"], S2, dict(reduction="none"))
     C["swift_hohenberg3d"] = ("SwiftHohenberg3DPDELoss", dict(domain_extent=6.0, num_points=6, dt=0.1), ["u"], S3, {})
     return C
 
@@ -122,7 +131,7 @@ def run_case(name, spec, mod):
         if dtype == torch.float64:
             loss_fn = loss_fn.double()
         total, d = loss_fn(*fields, **kw)
-        total.backward()
+        (total.sum() if total.dim() else total).backward()      # reduction='none' returns fields: their sum is differentiated
         if dt_name == "f64":
             for n, f in zip(fnames, fields):
                 out[f"in_{n}"] = f.detach().numpy()
@@ -141,7 +150,8 @@ def run_case(name, spec, mod):
         if isinstance(v, dict):
             return {k: jsonable(x) for k, x in v.items()}
         return v
-    meta = dict(cls=cls_name, kwargs=jsonable(kwargs), fields=fnames, shape=list(shape), extra_keys=list(extra))
+    meta = dict(cls=cls_name, kwargs=jsonable(kwargs), fields=fnames, shape=list(shape), extra_keys=list(extra),
+                plain_extra={k: v for k, v in extra.items() if isinstance(v, str) and v != "__c_field__"})
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     return out
 
@@ -164,6 +174,31 @@ def run_burgers_ghost():
         out[f"{dt_name}_res_v"] = rv.detach().numpy()
         out[f"{dt_name}_grad_pred"] = pred.grad.numpy()
     meta = dict(nu=0.03, dt=0.02, dx=0.11, dy=0.13)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out
+
+
+def run_flow_v2():
+    """eval/pde_loss_flow_v2.py: the three losses, the residual field and the gradients w.r.t. the prediction and the
+    boundary values (the module imports torch only)."""
+    sys.path.insert(0, os.path.join(REF, "eval"))
+    from pde_loss_flow_v2 import flow_mixing_pde_loss_v2
+    out = {}
+    B, T, H, W = 2, 5, 9, 12
+    meta = dict(vtmax=0.4, dt=0.01, Lx=1.0, Ly=0.8)
+    for dt_name, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        g = torch.Generator().manual_seed(2024)
+        mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).to(dtype).requires_grad_(True)
+        pred, bl, br, bb, bt = mk(B, T, H, W, 1), mk(B, T, H, 1, 1), mk(B, T, H, 1, 1), mk(B, T, 1, W, 1), mk(B, T, 1, W, 1)
+        loss, lt, la, res = flow_mixing_pde_loss_v2(pred, bl, br, bb, bt, **meta)
+        (loss + 0.5 * lt + 0.25 * la + 0.01 * res.sum()).backward()
+        if dt_name == "f64":
+            for n, x in (("pred", pred), ("left", bl), ("right", br), ("bottom", bb), ("top", bt)):
+                out[f"in_{n}"] = x.detach().numpy()
+        for n, x in (("loss", loss), ("loss_time", lt), ("loss_adv", la), ("residual", res)):
+            out[f"{dt_name}_{n}"] = x.detach().numpy()
+        for n, x in (("pred", pred), ("left", bl), ("right", br), ("bottom", bb), ("top", bt)):
+            out[f"{dt_name}_grad_{n}"] = x.grad.numpy()
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     return out
 
@@ -461,6 +496,14 @@ def main():
     import finetune.pde_loss_verified as mod
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if "--only" in sys.argv:      # --only name [name ...]: some fixtures of the class table, and/or flow_v2
+        for name in sys.argv[sys.argv.index("--only") + 1:]:
+            if name == "flow_v2":
+                np.savez_compressed(os.path.join(OUT, "flow_v2.npz"), **run_flow_v2())
+            else:
+                np.savez_compressed(os.path.join(OUT, f"pde_{name}.npz"), **run_case(name, cases()[name], mod))
+            print("wrote", name)
+        return
     if "--only-pins" in sys.argv:
         np.savez_compressed(os.path.join(OUT, "pins.npz"), **run_pins())
         print("wrote pins")
@@ -472,6 +515,8 @@ def main():
     for name, spec in cases().items():
         np.savez_compressed(os.path.join(OUT, f"pde_{name}.npz"), **run_case(name, spec, mod))
         print("wrote", name)
+    np.savez_compressed(os.path.join(OUT, "flow_v2.npz"), **run_flow_v2())
+    print("wrote flow_v2")
     np.savez_compressed(os.path.join(OUT, "pde_burgers2d_ghost.npz"), **run_burgers_ghost())
     print("wrote burgers2d_ghost")
     np.savez_compressed(os.path.join(OUT, "glue.npz"), **run_glue())
