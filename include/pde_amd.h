@@ -122,6 +122,16 @@ int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob,
                                              const float* upstream_total, double* sums, float* totals,
                                              float* const* grads, void* stream);
 
+/* pde_amd_residual_forward in double precision, for the offline tools that measure the residual scales of ground-truth
+ * trajectories in float64 (tools/compute_gt_scales_per_t.py:66-175, tools/test_gt_pde_*.py): near an exact solution the
+ * residual is a small difference of large terms and fp32 leaves a floor of about 1e-7 of the largest one.  Same PDEs, same
+ * formula (the fp32-rounded numeric literals included), fp64 arithmetic on fp64 tensors: fields, aux, sparams, weights
+ * [n_eqs][T_res], resid_out are double; consts: host array of prob->n_consts doubles used instead of prob->consts (which
+ * are floats); totals (nullable): double [n_eqs + 1].  No backward: the tools only evaluate. */
+int pde_amd_residual_forward_f64(const pde_amd_problem* prob, const double* consts, const double* const* fields,
+                                 const double* const* aux, const double* const* sparams, const double* weights, double* sums,
+                                 double* totals, double* const* resid_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement hook, no counterpart in the reference: the next launch of the register-blocked adjoint kernel issued from
  * this host thread (by pde_amd_residual_backward in recompute mode or by pde_amd_residual_forward_backward) records the
  * two HIP events (hipEvent_t, created with timing enabled) on its stream immediately before and after that one launch;

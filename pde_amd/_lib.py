@@ -61,6 +61,9 @@ SIGNATURES = {
     "pde_amd_residual_forward_backward_static": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                            C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                            C.POINTER(C.c_void_p), C.c_void_p]),
+    "pde_amd_residual_forward_f64": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_double), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "pde_amd_time_next_adjoint": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pde_amd_rescale_gradients": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pde_amd_pair_stats_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),

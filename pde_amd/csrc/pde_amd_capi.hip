@@ -3,6 +3,7 @@
 #include "stencil_kernels.hpp"
 #include "stencil_quad.hpp"
 #include "stencil_zmarch.hpp"
+#include "stencil_f64.hpp"
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
@@ -26,6 +27,8 @@ struct PdeVTable {
              const float* const*, const double*, const float* const*, float* const*, void*, size_t, hipStream_t);
   int (*fwd_bwd)(const pde_amd_problem*, const float* const*, const float* const*, const float* const*, const float*,
                  const float*, double*, float*, float* const*, void*, size_t, hipStream_t);
+  int (*fwd_f64)(const pde_amd_problem*, const double*, const double* const*, const double* const*, const double* const*,
+                 const double*, double*, double*, double* const*, void*, size_t, hipStream_t);
 };
 
 // grads[f] *= g / hint, skipped by every workgroup when the two are equal (both are device scalars)
@@ -293,6 +296,38 @@ struct Ops {
     }
   }
 
+  static int fwd_f64(const pde_amd_problem* p, const double* consts, const double* const* fields, const double* const* aux,
+                     const double* const* sparams, const double* weights, double* sums, double* totals,
+                     double* const* resid_out, void* ws, size_t ws_bytes_given, hipStream_t stream) {
+    int st = check(p);
+    if (st) return st;
+    if (!sums || !fields || (P::NC && !consts) || (P::NA && !aux) || (P::NSP && !sparams)) return PDE_AMD_EINVAL;
+    const long tr = p->frames - P::TLO - P::THI;
+    if (tr <= 0) {
+      (void)hipMemsetAsync(sums, 0, sizeof(double) * p->batch * P::NE, stream);
+      if (totals) (void)hipMemsetAsync(totals, 0, sizeof(double) * (P::NE + 1), stream);
+      return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+    }
+    if (!weights || !ws) return PDE_AMD_EINVAL;
+    const long nwg = (long)p->batch * tr;
+    if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+    if ((size_t)nwg * P::NE * sizeof(double) > ws_bytes_given) return PDE_AMD_EWORKSPACE;
+    Args64 a;
+    memset(&a, 0, sizeof(a));
+    for (int f = 0; f < P::NF; ++f) { if (!fields[f]) return PDE_AMD_EINVAL; a.f[f] = fields[f]; }
+    for (int x = 0; x < P::NA; ++x) a.aux[x] = aux[x];
+    for (int s = 0; s < P::NSP; ++s) a.sp[s] = sparams[s];
+    for (int c = 0; c < P::NC; ++c) a.c[c] = consts[c];
+    for (int k = 0; k < P::NE; ++k) a.rout[k] = resid_out ? resid_out[k] : nullptr;
+    a.wt = weights;
+    a.partial = reinterpret_cast<double*>(ws);
+    fill_geom(p, a.geo, 1, 1, 1);
+    hipLaunchKernelGGL((fwd_direct_f64_kernel<P>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((finalize_kernel<P::NE>), dim3(p->batch), dim3(256), 0, stream, a.partial, sums, (int)tr);
+    if (totals) hipLaunchKernelGGL((totals_f64_kernel<P::NE>), dim3(1), dim3(64), 0, stream, sums, totals, p->batch);
+    return launch_status();
+  }
+
   // Loss and gradient of one training step in one pass where the vector adjoint applies (it recomputes every residual
   // anyway and adds up weight * R^2 on the way); otherwise the forward and the backward launch one after the other.
   static int fwd_bwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
@@ -439,7 +474,7 @@ struct Ops {
     v.info.halo[2] = P::RH2 > P::RT2 ? P::RH2 : P::RT2;
     v.info.can_recompute = BwdMarchFits<P>::value ? 1 : 0;   // the quad adjoint is an accelerated form of the same mode
     v.info.name = P::NAME;
-    v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd; v.fwd_bwd = &fwd_bwd;
+    v.ws_bytes = &ws_bytes; v.fwd = &fwd; v.bwd = &bwd; v.fwd_bwd = &fwd_bwd; v.fwd_f64 = &fwd_f64;
     return v;
   }
 };
@@ -522,6 +557,15 @@ int pde_amd_residual_forward_backward(const pde_amd_problem* prob, const float* 
   const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
   if (!v) return PDE_AMD_EINVAL;
   return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
+int pde_amd_residual_forward_f64(const pde_amd_problem* prob, const double* consts, const double* const* fields,
+                                 const double* const* aux, const double* const* sparams, const double* weights, double* sums,
+                                 double* totals, double* const* resid_out, void* workspace, size_t workspace_bytes, void* stream) {
+  const PdeVTable* v = prob ? lookup(prob->pde_id) : nullptr;
+  if (!v) return PDE_AMD_EINVAL;
+  return v->fwd_f64(prob, consts, fields, aux, sparams, weights, sums, totals, resid_out, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
 }
 

@@ -117,6 +117,7 @@ __device__ __forceinline__ float to_vgpr(float x) {
 
 template <class P>
 struct SiteBase {
+  using real = float;        // the scalar type the generated code computes in
   float cv[MAXC];            // constants (only the first P::NC are ever set or read)
   float spv[MAXSP];          // per-sample parameters of this sample
   float uv[P::NU > 0 ? P::NU : 1];   // hoisted uniform subexpressions (P::uniforms); entries an accessor never reads are dead code

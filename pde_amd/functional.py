@@ -149,6 +149,30 @@ class HipBackend:
         _lib.check(st, f"residual_forward[{prob.spec}]")
         return totals, sums, resid
 
+    def forward_f64(self, prob: StencilProblem, fields, aux, sparams, weights):
+        """The residual forward in double precision on double tensors: (totals [n_eqs + 1], sums [B, n_eqs], residual fields)."""
+        f0 = fields[0]
+        if not f0.is_cuda:
+            raise RuntimeError("pde_amd: fields must be on a HIP device (there is no CPU fallback)")
+        L = _lib.lib()
+        s = SPECS[prob.spec]
+        cp = prob.c_struct(f0.shape)
+        B, T = f0.shape[0], f0.shape[1]
+        TR, ne = max(T - s.tlo - s.thi, 0), len(s.eqs)
+        sums = torch.empty((B, ne), dtype=torch.float64, device=f0.device)
+        totals = torch.empty((ne + 1,), dtype=torch.float64, device=f0.device)
+        resid = [torch.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float64, device=f0.device) for _ in range(ne)]
+        ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
+        ws = self._workspace(f0.device, ws_bytes)
+        consts = (C.c_double * max(len(prob.consts), 1))(*[float(v) for v in prob.consts])
+        with self._on(f0.device):
+            st = L.pde_amd_residual_forward_f64(C.byref(cp), consts, _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
+                                                _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()),
+                                                C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), _lib.ptr_array(resid, ne),
+                                                C.c_void_p(ws.data_ptr()), ws_bytes, self._stream(f0))
+        _lib.check(st, f"residual_forward_f64[{prob.spec}]")
+        return totals, sums, resid
+
     def backward(self, prob: StencilProblem, fields, aux, sparams, weights, upstream, upstream_sums, resid):
         f0 = fields[0]
         L = _lib.lib()
@@ -356,7 +380,17 @@ def _prepare(prob, fields, weights, sparams, aux):
 def residual_fields(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
                     sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = ()):
     """The raw residual of every equation as [B, T_res, *spatial] fp32 tensors (zero outside the residual lattice),
-    written by the forward kernel; no autograd."""
+    written by the forward kernel; no autograd.  Double-precision fields are evaluated in double precision (per-sample
+    parameters, auxiliary fields and weights are converted to match) and give double-precision residuals."""
+    if fields[0].dtype is torch.float64:
+        dev = fields[0].device
+        f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64).contiguous()
+        s = SPECS[prob.spec]
+        if len(fields) != len(s.fields) or len(sparams) != len(s.sparams) or len(aux) != len(s.aux):
+            raise ValueError(f"{prob.spec}: expected {len(s.fields)} fields, {len(s.sparams)} per-sample parameters, {len(s.aux)} aux fields")
+        if any(f.shape != fields[0].shape for f in fields):
+            raise ValueError(f"{prob.spec}: all fields must share one shape")
+        return _BACKEND.forward_f64(prob, [f64(f) for f in fields], tuple(f64(x) for x in aux), tuple(f64(p) for p in sparams), f64(weights))[2]
     fs, sp, ax, w = _prepare(prob, fields, weights, sparams, aux)
     _, _, resid = _BACKEND.forward(prob, [f.detach() for f in fs], tuple(ax), tuple(sp), w, True)
     return resid

@@ -145,12 +145,13 @@ class StencilPDELoss(nn.Module):
     def _sample_param(self, value, default, B: int, ref: Tensor) -> Tensor:
         if value is None:
             value = default
+        dt = torch.float64 if ref.dtype is torch.float64 else torch.float32      # fp64 fields: the fp64 residual evaluation
         if torch.is_tensor(value):
-            if value.dtype is torch.float32 and value.dim() == 1 and value.shape[0] == B and value.device == ref.device:
+            if value.dtype is dt and value.dim() == 1 and value.shape[0] == B and value.device == ref.device:
                 return value
-            v = value.to(device=ref.device, dtype=torch.float32).reshape(-1)
+            v = value.to(device=ref.device, dtype=dt).reshape(-1)
             return v.expand(B) if v.numel() == 1 else v
-        return torch.full((B,), float(value), dtype=torch.float32, device=ref.device)
+        return torch.full((B,), float(value), dtype=dt, device=ref.device)
 
     def _evaluate(self, fields: Sequence[Tensor], sparams: Sequence[Tensor] = (), aux: Sequence[Tensor] = (),
                   t_offset: Optional[Tensor] = None, reduction: str = "mean"):
@@ -171,6 +172,7 @@ class StencilPDELoss(nn.Module):
         if getattr(self, "_capture", None) is not None:      # residuals(): the fields themselves, no loss
             self._capture.update(zip(self.EQS, residual_fields(prob, fields, wt, sparams, aux)))
             self._capture["__sites_per_frame__"] = B * ext[0] * ext[1] * ext[2]
+            return None, {}
         mode = self.backward_mode
         if mode == "fused":
             hint = float(self.upstream_hint)
@@ -226,7 +228,9 @@ class StencilPDELoss(nn.Module):
     @torch.no_grad()
     def residuals(self, *args, **kwargs) -> Dict[str, Tensor]:
         """The raw residual field of every equation for the inputs forward() takes: {equation: [B, T_res, *spatial]}
-        fp32 (zero outside the residual lattice), plus '__sites_per_frame__' = lattice sites per residual frame."""
+        (zero outside the residual lattice), plus '__sites_per_frame__' = lattice sites per residual frame.  fp32, or fp64
+        when the fields are fp64: then the residuals are evaluated in double precision, as the reference's offline scale
+        tools do (tools/compute_gt_scales_per_t.py:66-175)."""
         self._capture = {}
         try:
             self.forward(*args, **kwargs)
@@ -736,7 +740,14 @@ class GrayScottPDELoss(StencilPDELoss):
         """Spectral Laplacian over the last two axes (:197-214).  The fields are real, so the half-spectrum transforms
         give the same result as the reference's fft2 / ifft2(...).real with half the work and no strided real-part view."""
         nk = self.K2.shape[1] // 2 + 1
-        negK2 = self._buf("negK2h", lambda: -self.K2[:, :nk].contiguous(), f.device)
+        if f.dtype is torch.float64:      # the fp64 residual evaluation: wavenumbers in double as well
+            def k2():
+                kx = torch.fft.fftfreq(self.nx, d=self.dx, dtype=torch.float64) * 2 * np.pi
+                ky = torch.fft.fftfreq(self.ny, d=self.dy, dtype=torch.float64) * 2 * np.pi
+                return -(kx[:, None] ** 2 + ky[None, :nk] ** 2)
+            negK2 = self._buf("negK2h64", k2, f.device)
+        else:
+            negK2 = self._buf("negK2h", lambda: -self.K2[:, :nk].contiguous(), f.device)
         return torch.fft.irfft2(negK2 * torch.fft.rfft2(f), s=f.shape[-2:])
 
     def forward(self, A: Tensor, B: Tensor, reduction: str = "mean"):
@@ -744,7 +755,8 @@ class GrayScottPDELoss(StencilPDELoss):
             A, B = A.unsqueeze(0), B.unsqueeze(0)
         if self.laplacian == "fd4":
             return self._evaluate([A, B], reduction=reduction)
-        lap = self.fft_laplacian(torch.stack([A.to(torch.float32), B.to(torch.float32)]))      # both fields in one batched transform
+        dt = torch.float64 if A.dtype is torch.float64 and getattr(self, "_capture", None) is not None else torch.float32
+        lap = self.fft_laplacian(torch.stack([A.to(dt), B.to(dt)]))      # both fields in one batched transform
         return self._evaluate([A, B, lap[0], lap[1]], reduction=reduction)
 
 

@@ -486,14 +486,12 @@ def hoist_uniforms(e: E, tab: UniformTable, memo=None) -> E:
 # ---------------------------------------------------------------------------
 
 def _flt(v: float) -> str:
-    import numpy as np
-    f = float(np.float32(v))
-    s = repr(f)
-    if "e" in s or "E" in s:
-        return s + "f"
-    if "." not in s and "inf" not in s and "nan" not in s:
+    """A literal in the scalar type of the accessor (R_ = typename A::real: float in the training kernels, double in the
+    fp64 residual kernel), written with all the digits of the double: the float kernels get its nearest float."""
+    s = repr(float(v))
+    if "e" not in s and "E" not in s and "." not in s and "inf" not in s and "nan" not in s:
         s += ".0"
-    return s + "f"
+    return f"R_({s})"
 
 
 class Emitter:
@@ -561,7 +559,7 @@ class Emitter:
         elif isinstance(e, Mul):
             s = "(" + " * ".join(self.expr(t) for t in e.factors) + ")"
         elif isinstance(e, Recip):
-            s = "(1.0f / " + self.expr(e.e) + ")"
+            s = "(R_(1.0) / " + self.expr(e.e) + ")"
         elif isinstance(e, Sel):
             # a call, so that both sides are values before the choice: the device compiler then emits one select;
             # with the ?: operator it builds divergent branches around the few multiply-adds of each side
@@ -574,7 +572,7 @@ class Emitter:
         # loads and shared subtrees become named temporaries
         if isinstance(e, (Ref, Aux, GRef)) or self.count.get(k, 0) > 1:
             name = f"t{len(self.names)}"
-            self.lines.append(f"const float {name} = {s};")
+            self.lines.append(f"const R_ {name} = {s};")
             self.names[k] = name
             return name
         return s

@@ -423,3 +423,59 @@ def check_shared_grad(dev):
     lc, _ = losses(pde_amd.shared_grad(c))
     lc.backward()
     assert torch.equal(c.grad.cpu(), b.grad.cpu())
+
+
+def check_residuals_f64(dev):
+    """Double-precision fields take the double-precision residual evaluation: the residual fields against the fp64 oracle
+    to rounding (1e-12, where the fp32 evaluation stops near 1e-6), and the scale accumulator on them against
+    tools/compute_gt_scales_per_t.py:109-152 restated in the oracle, to the same accuracy."""
+    import pde_amd
+    from pde_amd.scales import ResidualScaleAccumulator
+    from oracle import pde_oracle as PO
+    rng = np.random.default_rng(11)
+
+    def smooth(shape):
+        x = rng.standard_normal(shape)
+        for ax in range(1, len(shape)):
+            x = x + np.roll(x, 1, ax) + np.roll(x, -1, ax)
+        return x / 3.0 ** (len(shape) - 1)
+
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    tight = 1e-12
+    # Taylor-Green, per-sample viscosity
+    u, v, p = (smooth((2, 6, 8, 12)) for _ in range(3))
+    nu = np.array([0.02, 0.07])
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=12, ny=8, dt=0.01).to(dev)
+    got = fn.residuals(t64(u), t64(v), t64(p), nu=t64(nu))
+    want = PO.residuals_tg2d(torch.tensor(u), torch.tensor(v), torch.tensor(p), torch.tensor(nu), dx=2 * np.pi / 12, dy=2 * np.pi / 8, dt=0.01)
+    for eq, w in zip(fn.EQS, want):
+        assert got[eq].dtype == torch.float64
+        assert _rel(got[eq].cpu().numpy(), w.numpy()) <= tight, eq
+    r32 = fn.residuals(_t(u, dev), _t(v, dev), _t(p, dev), nu=_t(nu, dev))
+    assert r32["continuity"].dtype == torch.float32 and _rel(r32["x_momentum"].cpu().numpy(), want[1].numpy()) > 1e-9
+    # Gray-Scott with the spectral Laplacian (the scale tool's own case), two chunks; the transforms run in double as well
+    kw = dict(dx=2.0 / 16, dy=2.0 / 16, dt=0.5, F=0.098, k=0.057, D_A=1.81e-3, D_B=1.39e-3)
+    A, B = 0.5 + 0.2 * smooth((5, 7, 16, 16)), 0.3 + 0.2 * smooth((5, 7, 16, 16))
+    fn = pde_amd.GrayScottPDELoss(nx=16, ny=16, **kw).to(dev)
+    acc = ResidualScaleAccumulator(fn)
+    batches = []
+    for sl in (slice(0, 3), slice(3, 5)):
+        acc.update(t64(A[sl]), t64(B[sl]))
+        batches.append(PO.residuals_gray_scott_fft(torch.tensor(A[sl]), torch.tensor(B[sl]), **kw))
+    res = acc.result()
+    want = GO.gt_scales_per_t(batches, 16 * 16)
+    for k, eq in enumerate(res["eq_scales_per_t"]):
+        assert _rel(res["eq_scales_per_t"][eq].double().numpy(), want[k].float().double().numpy()) <= 1e-7, eq      # stored as fp32, like the tool's
+        assert abs(res["eq_scales"][eq] - float(torch.sqrt((want[k].double() ** 2).mean()))) <= 1e-7 * res["eq_scales"][eq]
+    # Rayleigh-Benard: walls and a cropped lattice
+    u, v, b = (smooth((2, 5, 16, 12)) for _ in range(3))
+    kap = np.array([1e-3, 5e-3])
+    kwr = dict(nx=16, ny=12, Lx=4.0, Ly=1.0, dt=0.25, skip_bl=3)
+    fn = pde_amd.RayleighBenardFullPDELoss(**kwr).to(dev)
+    got = fn.residuals(t64(u), t64(v), t64(b), kappa=t64(kap))
+    want = PO.residuals_rayleigh_benard(torch.tensor(u), torch.tensor(v), torch.tensor(b), torch.tensor(kap), dx=4.0 / 16, dy=1.0 / 11,
+                                        dt=0.25, skip_bl=3)
+    for eq, w in zip(fn.EQS, want):
+        g = got[eq].cpu().numpy()[..., 3:-3]
+        assert g.shape == tuple(w.shape) and _rel(g, w.numpy()) <= tight, eq
+        assert float(got[eq][..., :3].abs().max()) == 0.0 and float(got[eq][..., -3:].abs().max()) == 0.0

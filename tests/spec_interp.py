@@ -113,12 +113,12 @@ class InterpBackend:
             m = m & ok.reshape(view)
         return m
 
-    def _residuals(self, prob, fields, aux, sparams):
+    def _residuals(self, prob, fields, aux, sparams, f64=False):
         s = SPECS[prob.spec]
         F = [_to5(f, s.ndim) for f in fields]
         A = [x.detach().cpu().double().numpy().reshape((x.shape[0],) + (1,) * (3 - s.ndim) + tuple(x.shape[1:])) for x in aux]
         SP = [p.detach().cpu().double().numpy() for p in sparams]
-        C = [float(np.float32(c)) for c in prob.consts]
+        C = [float(c) if f64 else float(np.float32(c)) for c in prob.consts]      # the fp32 kernels round the constants
         B, T = F[0].shape[:2]
         TR = T - s.tlo - s.thi
         env = _Env(s, F, A, SP, C, T, lambda a, ot: a[:, s.tlo + ot: s.tlo + ot + TR])
@@ -147,6 +147,19 @@ class InterpBackend:
         for v in per_eq:
             tot = np.float32(tot + v)
         totals = torch.tensor(np.concatenate([per_eq, [tot]]), dtype=torch.float32, device=dev)
+        return totals, torch.tensor(sums, dtype=torch.float64, device=dev), resid
+
+    def forward_f64(self, prob, fields, aux, sparams, weights):
+        s, F, A, SP, C, R, TR = self._residuals(prob, fields, aux, sparams, f64=True)
+        w = weights.detach().cpu().double().numpy()
+        B = F[0].shape[0]
+        sums = np.zeros((B, len(s.eqs)))
+        for k, r in enumerate(R):
+            sums[:, k] = (r ** 2 * w[k].reshape(1, TR, 1, 1, 1)).reshape(B, -1).sum(1) if TR > 0 else 0.0
+        dev = fields[0].device
+        resid = [torch.tensor(r.reshape((B, TR) + tuple(fields[0].shape[2:])), dtype=torch.float64, device=dev) for r in R]
+        per_eq = sums.sum(0)
+        totals = torch.tensor(np.concatenate([per_eq, [per_eq.sum()]]), dtype=torch.float64, device=dev)
         return totals, torch.tensor(sums, dtype=torch.float64, device=dev), resid
 
     def backward(self, prob, fields, aux, sparams, weights, upstream, upstream_sums, resid):

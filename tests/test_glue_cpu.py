@@ -119,6 +119,10 @@ def test_rollout_host_logic():
 def test_scale_accumulator_host_logic():
     GC.check_scale_accumulator(CPU)
 
+def test_residuals_f64():
+    GC.check_residuals_f64(CPU)
+
+
 
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_host_logic(tag):

@@ -52,6 +52,10 @@ def test_rollout():
 def test_scale_accumulator():
     GC.check_scale_accumulator(DEV)
 
+def test_residuals_f64():
+    GC.check_residuals_f64(DEV)
+
+
 
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_golden(tag):
