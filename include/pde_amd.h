@@ -248,6 +248,16 @@ int pde_amd_scatter_field_grads(const float* const* field_grads, int64_t B, int6
 int pde_amd_pair_stats_affine(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
                               float rse_eps, const float* scale, const float* shift, double* stats, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The same with a by-product that lets ONE sweep over the model output serve a whole validation batch
+ * (finetune/train_taylor_green_2d_lora_v3.py:252-275: boundary RMSE, residual loss, VRMSE and RMSE of one `output`):
+ * the channels field_channels[f] of the de-normalised pred are also written as per-field tensors
+ * fields_out[f] = [groups][frames + 1][rows / frames] at frames 1..frames, which is the gather of compute_pde_loss
+ * (:183-195) minus its frame 0 (the input's first frame: the caller's to fill).  fields_out: host array of n_fields
+ * device pointers (n_fields = 0: none); rows must be a multiple of frames, the channels distinct. */
+int pde_amd_pair_stats_gather(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
+                              float rse_eps, const float* scale, const float* shift, double* stats, int64_t frames,
+                              const int32_t* field_channels, int32_t n_fields, float* const* fields_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int pde_amd_terms_forward_affine(const float* pred, const float* target, int64_t outer, const int32_t* dims,
                                  const pde_amd_term* terms, int32_t n_terms, const int32_t* indices, const float* scale,
                                  const float* shift, int64_t outer_per_sample, double* sums, void* workspace,

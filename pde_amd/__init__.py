@@ -19,7 +19,7 @@ from .boundary import (  # noqa: F401
 )
 from .metrics import (  # noqa: F401
     compute_vrmse, nrmse_per_sample, nrmse_per_channel, compute_rse, compute_mean_rse, metric_func, NRMSEAccumulator,
-    compute_pdebench_nrmse, LpLoss, FftLpLoss,
+    compute_pdebench_nrmse, LpLoss, FftLpLoss, validation_scalars,
 )
 from .glue import (  # noqa: F401
     gather_fields, create_pde_loss, compute_pde_loss_generic, PDE_LOSS_REGISTRY, compute_pde_loss_taylor_green_2d,

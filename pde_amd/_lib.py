@@ -78,6 +78,9 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pde_amd_pair_stats_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pde_amd_pair_stats_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p), C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
     "pde_amd_terms_forward_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(Term), C.c_int32,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pde_amd_terms_backward_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(Term), C.c_int32,

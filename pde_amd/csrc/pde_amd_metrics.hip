@@ -25,11 +25,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ------------------------------------------------------------------------------------------------
 constexpr int PS_UNROLL = 4;
 
+// Optional by-product of the pass: the channels ch[f] of pred (after the affine map) written out as per-field tensors
+// [groups][frames + 1][S] at frames 1..frames (frame 0 is the caller's: the trainers put the input's first frame there),
+// i.e. what gather_fields produces, without a second sweep over pred.  rows = frames * S.
+struct GatherSide {
+  float* fields[PDE_AMD_MAX_FIELDS];
+  int ch[PDE_AMD_MAX_FIELDS];
+  int nf;
+  long S, frames;
+};
+
 template <bool RSE>
 __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                            long rows, int C, int rows_per_step, long steps_per_block,
                                                            int blocks_per_group, float rse_eps, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, double* __restrict__ partial) {
+                                                           const float* __restrict__ shift, double* __restrict__ partial,
+                                                           const GatherSide gs) {
   extern __shared__ double s_acc[];          // [NSTAT][NT]
   const int NT = blockDim.x;
   const int g = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
@@ -44,6 +55,11 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
   float amax = 0.0f;
   long i = first;
+  // a thread's channel never changes, so it either feeds one field or none; element i is row i / C of the group, and a
+  // step of NT elements is rows_per_step rows
+  float* gdst = nullptr;
+  for (int f = 0; f < gs.nf; ++f)
+    if (gs.ch[f] == (int)(threadIdx.x % C)) gdst = gs.fields[f] + ((long)g * (gs.frames + 1) + 1) * gs.S + first / C;
   for (; i + (long)(PS_UNROLL - 1) * NT < last; i += (long)PS_UNROLL * NT) {
     float pv[PS_UNROLL], gv[PS_UNROLL];
 #pragma unroll
@@ -51,6 +67,11 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
     if (affine) {
 #pragma unroll
       for (int u = 0; u < PS_UNROLL; ++u) pv[u] = __fadd_rn(__fmul_rn(pv[u], sc), sh);
+    }
+    if (gdst) {
+#pragma unroll
+      for (int u = 0; u < PS_UNROLL; ++u) gdst[(long)u * rows_per_step] = pv[u];
+      gdst += (long)PS_UNROLL * rows_per_step;
     }
 #pragma unroll
     for (int u = 0; u < PS_UNROLL; ++u) {
@@ -63,6 +84,7 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
   }
   for (; i < last; i += NT) {
     const float pvv = affine ? __fadd_rn(__fmul_rn(p[i], sc), sh) : p[i], gvv = q[i];
+    if (gdst) { *gdst = pvv; gdst += rows_per_step; }
     const float d = pvv - gvv;
     const float d2 = d * d, g2 = gvv * gvv;
     a0 += (double)d2; a1 += (double)g2; a2 += (double)gvv; a3 += (double)pvv;
@@ -84,7 +106,6 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
     else { for (int t = c; t < NT; t += C) r = fmax(r, s_acc[s * NT + t]); }
     partial[((long)blockIdx.x * C + c) * NSTAT + s] = r;
   }
-  (void)rows_per_step;
 }
 
 // one wave per (group, channel, statistic): lanes stride over the workgroups' partials, then a fixed-order shuffle tree
@@ -392,6 +413,76 @@ __global__ __launch_bounds__(TILE_PTS) void scatter_tile_kernel(const GatherArgs
   }
 }
 
+// The statistics pass of pair_stats_kernel and the gather of gather_tile_kernel in one sweep: a workgroup takes whole
+// 256-site chunks of one sample's frames, both tensors pass through LDS images [256][C] as float4 rows, the gathered
+// channels leave as one float per lane (consecutive sites in consecutive lanes), and the statistics are accumulated from
+// the images by the first (256 / C) * C threads, whose channel (thread % C) then never changes.  Accumulation in fp64.
+// partial has the layout of pair_stats_kernel's, so the same finalize kernel follows.
+__global__ __launch_bounds__(TILE_PTS) void stats_gather_tile_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                                     int C, int blocks_per_group, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, double* __restrict__ partial,
+                                                                     const GatherSide gs) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // [2][TILE_PTS * C]; the statistics' scratch afterwards
+  float* const tp = tile;
+  float* const tq = tile + TILE_PTS * C;
+  const unsigned tid = threadIdx.x, NTS = (TILE_PTS / C) * C;
+  const int g = blockIdx.x / blocks_per_group, blk = blockIdx.x % blocks_per_group;
+  const long chunks = (gs.S + TILE_PTS - 1) / TILE_PTS, items = gs.frames * chunks;
+  const bool affine = scale != nullptr;
+  const unsigned cm = tid % C;
+  const float sc = affine ? scale[(long)g * C + cm] : 1.0f, sh = affine ? shift[(long)g * C + cm] : 0.0f;
+  float gsc[PDE_AMD_MAX_FIELDS], gsh[PDE_AMD_MAX_FIELDS];
+  for (int f = 0; f < gs.nf; ++f) {
+    gsc[f] = affine ? scale[(long)g * C + gs.ch[f]] : 1.0f;
+    gsh[f] = affine ? shift[(long)g * C + gs.ch[f]] : 0.0f;
+  }
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  float amax = 0.0f;
+  for (long item = blk; item < items; item += blocks_per_group) {
+    const long t = item / chunks;
+    const unsigned p0 = (unsigned)(item % chunks) * TILE_PTS;
+    const unsigned np = min((unsigned)TILE_PTS, (unsigned)gs.S - p0);
+    const long src = (((long)g * gs.frames + t) * gs.S + p0) * C;
+    const unsigned n4 = np * C / 4;
+    for (unsigned i = tid; i < n4; i += TILE_PTS) {
+      reinterpret_cast<f4*>(tp)[i] = reinterpret_cast<const f4*>(pred + src)[i];
+      reinterpret_cast<f4*>(tq)[i] = reinterpret_cast<const f4*>(target + src)[i];
+    }
+    __syncthreads();
+    if (tid < np) {
+      const long dst = ((long)g * (gs.frames + 1) + t + 1) * gs.S + p0 + tid;
+      for (int f = 0; f < gs.nf; ++f) {
+        float v = tp[tid * C + (unsigned)gs.ch[f]];
+        if (affine) v = __fadd_rn(__fmul_rn(v, gsc[f]), gsh[f]);
+        gs.fields[f][dst] = v;
+      }
+    }
+    if (tid < NTS) {
+      for (unsigned e = tid; e < np * C; e += NTS) {
+        const float pv = affine ? __fadd_rn(__fmul_rn(tp[e], sc), sh) : tp[e], gv = tq[e];
+        const float d = pv - gv;
+        a0 += (double)(d * d); a1 += (double)(gv * gv); a2 += (double)gv; a3 += (double)pv;
+        amax = fmaxf(amax, fabsf(d));
+      }
+    }
+    __syncthreads();
+  }
+  double* s_acc = reinterpret_cast<double*>(tile);      // [NSTAT][NTS]
+  if (tid < NTS) {
+    s_acc[0 * NTS + tid] = a0; s_acc[1 * NTS + tid] = a1; s_acc[2 * NTS + tid] = a2; s_acc[3 * NTS + tid] = a3;
+    s_acc[4 * NTS + tid] = 0.0; s_acc[5 * NTS + tid] = (double)amax;
+  }
+  __syncthreads();
+  for (unsigned w = tid; w < (unsigned)(NSTAT * C); w += TILE_PTS) {
+    const unsigned s = w / C, c = w % C;
+    double r = 0.0;
+    if (s < 5) { for (unsigned k = c; k < NTS; k += C) r += s_acc[s * NTS + k]; }
+    else { for (unsigned k = c; k < NTS; k += C) r = fmax(r, s_acc[s * NTS + k]); }
+    partial[((long)blockIdx.x * C + c) * NSTAT + s] = r;
+  }
+}
+
 // the tiled kernels need whole float4 rows per chunk and frame, and an LDS image of 256 points
 inline bool tile_path_ok(long S, int C, const void* p0, const void* p1) {
   return C <= 40 && (S * C) % 4 == 0 && (TILE_PTS * C) % 4 == 0 && S < (1L << 31) &&
@@ -482,7 +573,26 @@ int pde_amd_pair_stats(const float* pred, const float* target, int64_t groups, i
 int pde_amd_pair_stats_affine(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
                               float rse_eps, const float* scale, const float* shift, double* stats, void* workspace,
                               size_t workspace_bytes, void* stream) {
+  return pde_amd_pair_stats_gather(pred, target, groups, rows, channels, rse_eps, scale, shift, stats, 0, nullptr, 0, nullptr,
+                                   workspace, workspace_bytes, stream);
+}
+
+int pde_amd_pair_stats_gather(const float* pred, const float* target, int64_t groups, int64_t rows, int32_t channels,
+                              float rse_eps, const float* scale, const float* shift, double* stats, int64_t frames,
+                              const int32_t* field_channels, int32_t n_fields, float* const* fields_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if ((scale == nullptr) != (shift == nullptr)) return PDE_AMD_EINVAL;
+  GatherSide gs = {};
+  if (n_fields != 0) {
+    if (n_fields < 0 || n_fields > PDE_AMD_MAX_FIELDS || !field_channels || !fields_out || frames <= 0 || rows % frames != 0) return PDE_AMD_EINVAL;
+    gs.nf = n_fields; gs.frames = frames; gs.S = rows / frames;
+    for (int f = 0; f < n_fields; ++f) {
+      if (field_channels[f] < 0 || field_channels[f] >= channels || !fields_out[f]) return PDE_AMD_EINVAL;
+      for (int k = 0; k < f; ++k)
+        if (field_channels[k] == field_channels[f]) return PDE_AMD_EINVAL;      // one field per channel
+      gs.ch[f] = field_channels[f]; gs.fields[f] = fields_out[f];
+    }
+  }
   if (groups == 0 || rows == 0) {
     if (groups < 0 || rows < 0 || channels <= 0) return PDE_AMD_EINVAL;
     if (groups > 0 && stats) (void)hipMemsetAsync(stats, 0, (size_t)groups * channels * NSTAT * sizeof(double), (hipStream_t)stream);
@@ -494,14 +604,26 @@ int pde_amd_pair_stats_affine(const float* pred, const float* target, int64_t gr
   if (workspace_bytes < pde_amd_pair_stats_workspace_bytes(groups, rows, channels)) return PDE_AMD_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)workspace;
+  if (gs.nf > 0 && rse_eps < 0.0f && tile_path_ok(gs.S, channels, pred, target) && TILE_PTS / channels >= 1 &&
+      (size_t)NSTAT * TILE_PTS * sizeof(double) <= (size_t)2 * TILE_PTS * channels * sizeof(float)) {
+    // one sweep with coalesced field writes; a sample's (frame, chunk) items are dealt to at most as many workgroups as the
+    // workspace was sized for
+    const long items = gs.frames * ((gs.S + TILE_PTS - 1) / TILE_PTS);
+    const int bpg = (int)(items < pl.blocks_per_group ? items : pl.blocks_per_group);
+    hipLaunchKernelGGL(stats_gather_tile_kernel, dim3((unsigned)(groups * bpg)), dim3(TILE_PTS), (size_t)2 * TILE_PTS * channels * sizeof(float),
+                       st, pred, target, (int)channels, bpg, scale, shift, partial, gs);
+    hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)((NSTAT * channels + 3) / 4), (unsigned)groups), dim3(256), 0, st, partial,
+                       bpg, (int)channels, stats);
+    return check_launch();
+  }
   const size_t lds = (size_t)NSTAT * pl.nt * sizeof(double);
   // a negative rse_eps leaves the relative-squared-error statistic out (0): its division is a fifth of the kernel's arithmetic
   if (rse_eps >= 0.0f)
     hipLaunchKernelGGL(pair_stats_kernel<true>, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
-                       (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial);
+                       (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial, gs);
   else
     hipLaunchKernelGGL(pair_stats_kernel<false>, dim3((unsigned)(groups * pl.blocks_per_group)), dim3(pl.nt), lds, st, pred, target, (long)rows,
-                       (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial);
+                       (int)channels, pl.nt / channels, pl.steps_per_block, pl.blocks_per_group, rse_eps, scale, shift, partial, gs);
   hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3((unsigned)((NSTAT * channels + 3) / 4), (unsigned)groups), dim3(256), 0, st, partial,
                      pl.blocks_per_group, (int)channels, stats);
   return check_launch();

@@ -55,6 +55,32 @@ def compute_vrmse(output, target, channel_mask) -> Tuple[torch.Tensor, torch.Ten
     return vrmse.to(torch.float32), rmse.to(torch.float32)
 
 
+@torch.no_grad()
+def validation_scalars(output, input_data, target, channel_mask, pde_loss_fn, field_channels: Sequence[int], bc_width: int = 1,
+                       **loss_kwargs):
+    """The four numbers validate() adds up per batch (finetune/train_taylor_green_2d_lora_v3.py:252-275):
+    (bc_loss, pde_loss, rmse, vrmse) = compute_boundary_loss, compute_pde_loss[0] and compute_vrmse of one model output,
+    with ONE sweep over that output: the statistics pass also writes the fields of the residual loss (the gather), and the
+    boundary strips are a few rows.  `output` may be a Denormalised (std and mean applied while reading).  loss_kwargs are
+    handed to pde_loss_fn after the fields (nu=..., t_offset=...).  bc_loss and pde_loss equal the separate functions' bit for
+    bit, rmse and vrmse to the rounding of their fp64 sums (another summation order)."""
+    from .boundary import compute_boundary_loss
+    from .sink import unwrap
+    out, affine = unwrap(output)
+    ch = valid_channels(channel_mask)
+    stats, fields = R.get_backend().pair_stats_gather(out.detach(), target, input_data.detach().float().contiguous(), field_channels, affine)
+    rows = out.numel() // int(out.shape[-1])
+    st = stats.sum(0)
+    if len(ch) <= 64:
+        vr = R.get_backend().vrmse_from_stats(st, ch, rows)
+        vrmse, rmse = vr[0], vr[1]
+    else:
+        vrmse, rmse = compute_vrmse(output, target, channel_mask)
+    pde_loss, _ = pde_loss_fn(*fields, **loss_kwargs)
+    bc_loss = compute_boundary_loss(output, target, channel_mask, bc_width)
+    return bc_loss, pde_loss, rmse, vrmse
+
+
 def nrmse_per_sample(pred, gt) -> torch.Tensor:
     """tools/eval_rollout.py:60-72 — [M, ...] -> [M]: sqrt(sum (p-g)^2 / (sum g^2 + 1e-12)) over everything but M."""
     M = int(pred.shape[0])

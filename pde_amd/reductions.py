@@ -66,6 +66,29 @@ class HipReductions:
                                                stats.data_ptr(), ws.data_ptr(), nbytes, _stream(pred)), "pair_stats")
         return stats
 
+    def pair_stats_gather(self, pred, target, input_data, channels: Sequence[int], affine=None):
+        """One sweep over pred [B, T, *spatial, C]: the per-sample statistics [B, C, NSTAT] and, as a by-product, the fields
+        gather_fields(pred, input_data, channels) would produce ([B, T + 1, *spatial] each, frame 0 from input_data[:, 0])."""
+        l = _lib.lib()
+        pred, target = _f32c(pred, "pred"), _f32c(target, "target")
+        B, T, Cn = int(pred.shape[0]), int(pred.shape[1]), int(pred.shape[-1])
+        spatial = tuple(pred.shape[2:-1])
+        rows = pred.numel() // max(B * Cn, 1)
+        if target.shape != pred.shape or input_data.shape[0] != B or tuple(input_data.shape[2:]) != spatial + (Cn,):
+            raise ValueError("pair_stats_gather: pred, target [B, T, *spatial, C] and input_data [B, T_in, *spatial, C] do not match")
+        stats = torch.empty((B, Cn, NSTAT), dtype=torch.float64, device=pred.device)
+        fields = [torch.empty((B, T + 1) + spatial, dtype=torch.float32, device=pred.device) for _ in channels]
+        for f, c in zip(fields, channels):      # frame 0: a strip of the input (the gather of the reference's preamble)
+            f[:, 0].copy_(input_data[:, 0, ..., int(c)])
+        nbytes = l.pde_amd_pair_stats_workspace_bytes(B, rows, Cn)
+        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
+        sc, sh, _ = _affine_args(affine, B)
+        ch = (C.c_int32 * max(len(channels), 1))(*[int(c) for c in channels])
+        _lib.check(l.pde_amd_pair_stats_gather(pred.data_ptr(), target.data_ptr(), B, rows, Cn, -1.0, sc, sh, stats.data_ptr(), T, ch,
+                                               len(channels), _lib.ptr_array(fields, len(fields)), ws.data_ptr(), nbytes, _stream(pred)),
+                   "pair_stats_gather")
+        return stats, fields
+
     def vrmse_from_stats(self, stats, valid: Sequence[int], rows: int):
         """[2] fp32 (vrmse, rmse) from one group's statistics [C, NSTAT]; at most 64 valid channels."""
         out = torch.empty(2, dtype=torch.float32, device=stats.device)

@@ -479,3 +479,30 @@ def check_residuals_f64(dev):
         g = got[eq].cpu().numpy()[..., 3:-3]
         assert g.shape == tuple(w.shape) and _rel(g, w.numpy()) <= tight, eq
         assert float(got[eq][..., :3].abs().max()) == 0.0 and float(got[eq][..., -3:].abs().max()) == 0.0
+
+
+def check_validation_scalars(dev):
+    """validation_scalars (one sweep over the output) against the separate functions validate() calls
+    (finetune/train_taylor_green_2d_lora_v3.py:252-275), on a plain output and on a Denormalised one: the boundary and
+    residual losses bit for bit, RMSE and VRMSE to the rounding of their fp64 sums."""
+    import pde_amd
+    gen = torch.Generator().manual_seed(17)
+    B, T, H, W, C = 3, 4, 12, 20, 18
+    on = torch.randn(B, T, H, W, C, generator=gen).to(dev)
+    inp = torch.randn(B, 2, H, W, C, generator=gen).to(dev)
+    tgt = torch.randn(B, T, H, W, C, generator=gen).to(dev)
+    mean = (0.3 * torch.randn(B, 1, 1, 1, C, generator=gen)).to(dev)
+    std = (0.5 + torch.rand(B, 1, 1, 1, C, generator=gen)).to(dev)
+    mask = torch.zeros(B, C)
+    mask[:, [0, 1, 15]] = 1
+    mask = mask.to(dev)
+    nu = torch.tensor([0.02, 0.07, 0.04]).to(dev)
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=W, ny=H, dt=0.01).to(dev)
+    for make in (lambda: on, lambda: pde_amd.Denormalised(on, mean, std)):
+        with torch.no_grad():
+            o = make()
+            want = (PB.compute_boundary_loss(o, tgt, mask, 2), PG.compute_pde_loss_taylor_green_2d(o, inp, fn, nu)[0],
+                    *reversed(PM.compute_vrmse(o, tgt, mask)))
+        got = pde_amd.validation_scalars(make(), inp, tgt, mask, fn, (0, 1, 15), bc_width=2, nu=nu)
+        for a, b, name in zip(got, want, ("bc", "pde", "rmse", "vrmse")):      # the statistics are added in another order: fp64 rounding
+            assert float(a) == float(b) if name in ("bc", "pde") else abs(float(a) - float(b)) <= 1e-6 * abs(float(b)), (name, float(a), float(b))

@@ -53,6 +53,12 @@ class InterpReductions:
         st[..., R.S_MAXD] = np.abs(d).max(1) if rows else 0.0
         return torch.tensor(st, dtype=torch.float64, device=pred.device)
 
+    def pair_stats_gather(self, pred, target, input_data, channels, affine=None):
+        B, Cn = int(pred.shape[0]), int(pred.shape[-1])
+        rows = pred.numel() // (B * Cn)
+        stats = self.pair_stats(pred, target, B, rows, Cn, affine=affine)
+        return stats, self.gather_fields(pred.detach().float(), input_data.detach().float(), channels, False, affine)
+
     @staticmethod
     def _term_offsets(dims, t, pool):
         lists = [pool[t.idx_off[k]: t.idx_off[k] + t.n[k]] for k in range(4)]

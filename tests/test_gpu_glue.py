@@ -56,6 +56,10 @@ def test_residuals_f64():
     GC.check_residuals_f64(DEV)
 
 
+def test_validation_scalars_single_sweep():
+    GC.check_validation_scalars(DEV)
+
+
 
 @pytest.mark.parametrize("tag", ["1d", "2d", "3d"])
 def test_metric_func_golden(tag):
