@@ -96,11 +96,16 @@ def main():
         e_in = nf
         for v in shape:
             e_in *= v
-        gbs = 12 * e_in / ms / 1e6
+        # algorithmic bytes of a step: forward reads the fields (4 E_in), backward reads them again and writes the gradients
+        # (8 E_in): 12 E_in.  The fused step is one pass, read + write = 8 E_in; where a PDE has no fused kernel the mode
+        # falls back to forward + backward and 12 E_in stays the right count (the 8 E_in column is then an underestimate).
+        fused = mod.backward_mode == "fused"
+        alg = (8 if fused else 12) * e_in
+        gbs = alg / ms / 1e6
         gbs_f = 4 * e_in / ms_f / 1e6
         rows.append(dict(case=tag, cls=cls_name, shape=list(shape), fields=nf, ms_fwd_bwd=ms, ms_fwd=ms_f, gbs_fwd_bwd=gbs, gbs_fwd=gbs_f,
-                         mode=mod.backward_mode))
-        print(f"{tag:28s} {str(tuple(shape)):22s} F={nf}  fwd+bwd {ms:8.3f} ms {gbs:7.0f} GB/s ({gbs / 80:4.1f}% of 8 TB/s)   fwd {ms_f:7.3f} ms {gbs_f:6.0f} GB/s")
+                         mode=mod.backward_mode, algorithmic_bytes=alg, e_in_bytes_factor=8 if fused else 12))
+        print(f"{tag:28s} {str(tuple(shape)):22s} F={nf}  fwd+bwd {ms:8.3f} ms {gbs:7.0f} GB/s of {'8' if fused else '12'} E_in ({gbs / 80:4.1f}% of 8 TB/s)   fwd {ms_f:7.3f} ms {gbs_f:6.0f} GB/s")
     if "--json" in sys.argv:
         os.makedirs("gpurun_out", exist_ok=True)
         json.dump(rows, open("gpurun_out/bench_all.json", "w"), indent=1)
