@@ -129,6 +129,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed steps (on top of --warmup) until this much wall time has passed, so that the timed steps "
+                         "run at the clocks of a busy GPU; 0 = none")
     ap.add_argument("--rotate", type=int, default=4,
                     help="number of independent input sets the steps cycle through; 4 sets (805 MB of fields, as much again of "
                          "gradients) exceed the 256 MiB Infinity Cache, so every step reads its fields from HBM ('cold'); "
@@ -270,13 +273,28 @@ def main(argv=None):
             j = i % len(graphs)
             graphs[j].replay()
             return pdist.reduce_packed_async(keys, g_bufs[j], force=distributed)
-        backend.backward_events, backend.forward_events = bwd_events, fwd_events
+        # fused mode has no forward launch to time, and with only the adjoint timer armed the step keeps the C++ operator
+        backend.backward_events, backend.forward_events = bwd_events, (None if args.mode == "fused" else fwd_events)
         buf, names = loss_step(i % n_sets)
         backend.backward_events = backend.forward_events = None
         # the step's scalars: one packed all-reduce, started now and joined a step later so that it runs beside the next step
         return pdist.reduce_packed_async(names, buf, force=distributed)
 
     backend.backward_event_pool, backend.forward_event_pool = pool(n_probe + 40), pool(n_probe + 40)
+    # A few dozen 0.15 ms steps do not bring an idle GPU up to its working clocks (the same kernel measures 10 % slower in
+    # the first milliseconds of activity): more untimed steps of the very same kind, until settle-ms have passed.
+    settle_steps = 0
+    if args.settle_ms > 0:
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < args.settle_ms:
+            for j in range(16):
+                if graph is not None:
+                    graphs[(settle_steps + j) % len(graphs)].replay()
+                else:
+                    loss_step((settle_steps + j) % n_sets)
+            settle_steps += 16
+            torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -313,7 +331,7 @@ def main(argv=None):
         other = {}
         if n_sets > 1:
             warm = []
-            backend.backward_events, backend.forward_events = warm, []
+            backend.backward_events, backend.forward_events = warm, (None if args.mode == "fused" else [])
             for _ in range(24):
                 loss_step(0)
             backend.backward_events = backend.forward_events = None
@@ -327,6 +345,7 @@ def main(argv=None):
         out = {
             "metric": "PDE-residual loss fwd+bwd grid-points/sec",
             "value": value, "unit": "grid-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",

@@ -408,8 +408,14 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
     scalar); backward hands the gradient out, rescaled on the device if the upstream value differs.
     """
     be = _BACKEND
-    if type(be) is HipBackend and _HOST == "op" and be.backward_events is None and be.forward_events is None:
-        # the C++ operator: same kernels, same results; checks, conversions and the autograd node in C++
+    # The C++ operator: same kernels, same results; checks, conversions and the autograd node in C++.  While launches are
+    # being timed it still serves the fused step, whose adjoint is launched from this thread, inside the call (the
+    # library records the events around that launch); the other modes launch their adjoint from autograd's thread, where
+    # only the Python function can arm the timer.
+    timed = be.backward_events is not None or be.forward_events is not None if type(be) is HipBackend else False
+    fused_timed = timed and type(mode) is tuple and mode[0] == "fused" and be.forward_events is None and torch.is_grad_enabled() \
+        and be.can_recompute(prob.spec) and any(f.requires_grad for f in fields)
+    if type(be) is HipBackend and _HOST == "op" and (not timed or fused_timed):
         assumed = None
         if type(mode) is tuple:
             mode, assumed = mode
@@ -417,7 +423,11 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
             can = be.can_recompute(prob.spec)
             if mode == "auto" or not can:
                 mode = "recompute" if mode == "auto" and can else "stored"
-        out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed)
+        ev = be._arm_adjoint_timer() if fused_timed else None
+        try:
+            out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed)
+        finally:
+            be._disarm_adjoint_timer(ev)
         return out[:-1], out[-1]
     fs, sp, ax, w = _prepare(prob, fields, weights, sparams, aux)
     if not torch.is_grad_enabled():      # inside Function.forward the grad mode is always off, so it is passed in

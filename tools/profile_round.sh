@@ -8,8 +8,8 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/${tag}_stats.log 2>&1 || { echo "stats run failed"; tail -5 $out/${tag}_stats.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $out/${tag}_fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $out/${tag}_write.log 2>&1 || { echo "write pass failed"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-graph > $out/${tag}_fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-graph > $out/${tag}_write.log 2>&1 || { echo "write pass failed"; exit 1; }
 python3 - "$out" "$tag" <<'PY' | tee $out/${tag}_summary.txt
 import csv, glob, sys, collections, json
 out, tag = sys.argv[1], sys.argv[2]
