@@ -12,10 +12,17 @@ from pde_amd.stencil.specs import SPECS
 dev = torch.device("cuda:0")
 
 
-def timeit(fn, n=15, warm=3):
+def timeit(fn, n=15, warm=3, settle_ms=150.0):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    # an idle GPU reaches its working clocks only after a while of activity (the same kernel measures 10 % slower before)
+    import time
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in evs:
         a.record(); fn(); b.record()
