@@ -169,6 +169,9 @@ struct Ops {
     for (int c = 0; c < P::NC; ++c) a.c[c] = p->consts[c];
   }
 
+  // the plane-marching forward runs where the time-marching one does not fit LDS, or where the spec prefers it
+  static constexpr bool ZFWD = ZCfg<P, P::ZW>::FWD_OK && (P::ZFIRST != 0 || !QuadCfg<P, P::QWF>::FWD_OK);
+
   static int fwd(const pde_amd_problem* p, const float* const* fields, const float* const* aux,
                  const float* const* sparams, const float* weights, double* sums, float* totals,
                  float* const* resid_out, void* ws, size_t ws_bytes_given, hipStream_t stream) {
@@ -196,7 +199,7 @@ struct Ops {
         a.rout[k] = resid_out[k];
       }
       bool launched = false;
-      if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && ZCfg<P, P::ZW>::FWD_OK) {
+      if constexpr (ZFWD) {
         if (p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NE, P::ZW>(resid_out)) {
           items = launch_plane_forward<true>(p, a, tr, stream);
           if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
@@ -205,7 +208,7 @@ struct Ops {
         }
       }
       if constexpr (QuadCfg<P, P::QWF>::FWD_OK) {
-        if (quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
+        if (!launched && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) && aligned_vec<P::NE, P::QWF>(resid_out) &&
             (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {
           fill_geom(p, a.geo, P::QF0, P::QF1, P::QF2);
           const long qtiles = (long)a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
@@ -232,8 +235,8 @@ struct Ops {
         if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
         hipLaunchKernelGGL((fwd_kernel<P, true>), dim3((unsigned)(p->batch * items)), dim3(P::NT), 0, stream, a);
       }
-    } else if (!QuadCfg<P, P::QWF>::FWD_OK && ZCfg<P, P::ZW>::FWD_OK && p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields)) {
-      if constexpr (!QuadCfg<P, P::QWF>::FWD_OK && ZCfg<P, P::ZW>::FWD_OK) {
+    } else if (ZFWD && p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields)) {
+      if constexpr (ZFWD) {
         items = launch_plane_forward<false>(p, a, tr, stream);
         if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
         if (items < 0) return PDE_AMD_ESHAPE;

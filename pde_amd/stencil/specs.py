@@ -53,6 +53,7 @@ class Spec:
     z_tile: Tuple[int, int] = (0, 0)
     z_threads: int = 256
     z_width: int = 2
+    z_first: bool = False           # forward: prefer the plane-marching kernel to the time-marching one
     hoist_uniforms: bool = True     # precompute products/sums of constants and per-sample parameters once per sample
     quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
 
@@ -455,7 +456,9 @@ def _advection3d():
     u = b.F()
     a, bb, c = b.s("a"), b.s("b"), b.s("c")
     R = _ddt(b, u) + a * _d1c4(b, u, 0, "dx") + bb * _d1c4(b, u, 1, "dy") + c * _d1c4(b, u, 2, "dz")
-    return b.done([R], **T3D)
+    # plane-marching forward and adjoint: measured 45 / 61 / 72 us against 84 / 93 / 105 us for the time-marching forward
+    # (without / with residual output) and the per-frame adjoint on [2, 9, 128^3]
+    return b.done([R], **{**T3D, **Z3D, "z_first": True})
 
 
 def _ape_burgers3d():
@@ -483,7 +486,7 @@ def _swift_hohenberg3d():
     lap = lambda q: _d2c2(b, q, 0, "dx") + _d2c2(b, q, 1, "dx") + _d2c2(b, q, 2, "dx")
     lu = lap(u)
     R = _ddt(b, u) - lin * u + twok * lu + lap(lu) - u * u + u * u * u
-    return b.done([R], **T3D)
+    return b.done([R], **{**T3D, **Z3D, "z_first": True})
 
 
 def _heat3d():
