@@ -247,6 +247,22 @@ def get_backend():
     return _BACKEND
 
 
+def resolve_mode(mode: str, spec: str) -> str:
+    """'auto' and 'fused' -> the kernels that run: 'recompute' (forward kernel, then an adjoint that re-evaluates the
+    residuals), 'stored' (forward writes the residuals, the adjoint reads them) or 'fused' (one pass).  'auto' recomputes
+    where the PDE allows it, unless its spec says the stored kernels measured faster; 'fused' needs the recomputing adjoint
+    and yields to whichever of the other two the spec marks as faster for that PDE."""
+    if mode not in ("auto", "fused"):
+        return mode
+    s = SPECS[spec]
+    can = _BACKEND.can_recompute(spec)
+    if not can or s.auto_stored:
+        return "stored"
+    if mode == "fused" and not s.fused_slower:
+        return "fused"
+    return "recompute"
+
+
 class _ResidualLosses(torch.autograd.Function):
     """outputs: totals[0], ..., totals[n_eqs] as 0-dim tensors, then sums[B, n_eqs]."""
 
@@ -258,10 +274,7 @@ class _ResidualLosses(torch.autograd.Function):
         assumed = None
         if isinstance(mode, tuple):      # ('fused', device scalar): the upstream gradient of the total to assume
             mode, assumed = mode
-        if mode == "fused" and not _BACKEND.can_recompute(prob.spec):
-            mode = "stored"
-        if mode == "auto":
-            mode = "recompute" if _BACKEND.can_recompute(prob.spec) else "stored"
+        mode = resolve_mode(mode, prob.spec)
         ctx.ghat = ctx.assumed = None
         if need_grad and mode == "fused":
             # loss and gradient in one pass; the gradient is handed out in backward, rescaled if autograd delivers
@@ -413,16 +426,13 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
     # library records the events around that launch); the other modes launch their adjoint from autograd's thread, where
     # only the Python function can arm the timer.
     timed = be.backward_events is not None or be.forward_events is not None if type(be) is HipBackend else False
-    fused_timed = timed and type(mode) is tuple and mode[0] == "fused" and be.forward_events is None and torch.is_grad_enabled() \
-        and be.can_recompute(prob.spec) and any(f.requires_grad for f in fields)
+    fused_timed = timed and type(mode) is tuple and resolve_mode(mode[0], prob.spec) == "fused" and be.forward_events is None \
+        and torch.is_grad_enabled() and any(f.requires_grad for f in fields)
     if type(be) is HipBackend and _HOST == "op" and (not timed or fused_timed):
         assumed = None
         if type(mode) is tuple:
             mode, assumed = mode
-        if mode == "auto" or mode == "fused":
-            can = be.can_recompute(prob.spec)
-            if mode == "auto" or not can:
-                mode = "recompute" if mode == "auto" and can else "stored"
+        mode = resolve_mode(mode, prob.spec)
         ev = be._arm_adjoint_timer() if fused_timed else None
         try:
             out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed)
