@@ -220,10 +220,12 @@ def main(argv=None):
         for f in fields:
             f.grad = None
         total, losses = loss_fn(*fields, nu=nu)
-        total.backward(gradient=one)      # the upstream gradient of the loss: a resident 1.0 instead of a fill launch per step
-        # the step's scalars as one vector, ready for the packed all-reduce (detached: nothing of the autograd graph
-        # outlives the step, so a later capture on another stream starts clean)
-        return pdist.pack_scalars({"total": total, **losses}), ["total", *losses]
+        # the upstream gradient of the loss: the module's own resident scalar (upstream_hint = 1.0) instead of a fill launch
+        # per step; handed the very tensor it assumed, the fused step knows without looking that no rescaling is due
+        total.backward(gradient=loss_fn.upstream_scalar(dev) if args.mode == "fused" else one)
+        # the step's scalars as one vector, ready for the packed all-reduce: they already sit side by side in the buffer the
+        # reduction kernel wrote, so this is a view, not a launch (detached: nothing of the autograd graph outlives the step)
+        return pdist.pack_scalars_named({"total": total, **losses})
 
     for i in range(max(args.warmup, n_sets)):
         buf, keys = loss_step(i % n_sets)
@@ -258,7 +260,7 @@ def main(argv=None):
             torch.cuda.synchronize()
     graph = graphs[0] if graphs else None
     # an eager probe step costs more than a replayed one (the host cannot keep up), so only every 10th step is one
-    probe = max(2, min(10, args.steps // 3))
+    probe = 10 if args.steps >= 10 else max(2, args.steps // 2)
     if n_sets > 1 and probe % n_sets == 0:
         probe += 1                       # the probes visit every input set in turn
     n_probe = (args.steps + probe - 1) // probe

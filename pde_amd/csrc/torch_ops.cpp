@@ -163,11 +163,12 @@ struct ResidualLosses : public torch::autograd::Function<ResidualLosses> {
       grads = it->second.toTensorVector();      // computed in forward for the assumed upstream value: rescale if it differs
       ctx->saved_data.erase(it);                // handed out once; a second backward recomputes
       const at::Tensor up = gouts[ne].to(at::kFloat).contiguous();
-      float* pg[PDE_AMD_MAX_FIELDS] = {};
-      for (int i = 0; i < nf; ++i) pg[i] = grads[i].data_ptr<float>();
-      check(abi.rescale(pg, nf, grads[0].numel(), up.data_ptr<float>(), ctx->saved_data["assumed"].toTensor().data_ptr<float>(),
-                        stream.stream()),
-            "rescale_gradients");
+      const at::Tensor assumed = ctx->saved_data["assumed"].toTensor();
+      if (up.data_ptr() != assumed.data_ptr()) {      // handed the assumed scalar itself: nothing to compare on the device
+        float* pg[PDE_AMD_MAX_FIELDS] = {};
+        for (int i = 0; i < nf; ++i) pg[i] = grads[i].data_ptr<float>();
+        check(abi.rescale(pg, nf, grads[0].numel(), up.data_ptr<float>(), assumed.data_ptr<float>(), stream.stream()), "rescale_gradients");
+      }
     } else {
       std::vector<at::Tensor> ups((size_t)ne + 1);
       const float* pu[PDE_AMD_MAX_EQS + 1] = {};

@@ -64,6 +64,24 @@ def pack_scalars(values: Dict[str, torch.Tensor]) -> torch.Tensor:
     return torch.stack([v.detach().reshape(()) for v in values.values()]).to(torch.float64)
 
 
+def pack_scalars_named(values: Dict[str, torch.Tensor]):
+    """(vector, names): pack_scalars without any kernel when the scalars already sit side by side in one buffer, as the
+    per-equation losses and the total of a residual loss do (one small tensor written by the reduction kernel): the vector
+    is then a view of that buffer, in the buffer's order and dtype, and `names` says which entry is which.  The caller
+    owns the buffer: an in-place all-reduce on the view rewrites the step's own scalars, which is what logging wants.
+    Anything else takes pack_scalars."""
+    names = list(values)
+    vs = [v.detach() for v in values.values()]
+    if vs and all(v.dim() == 0 and v.dtype == vs[0].dtype and v.device == vs[0].device for v in vs):
+        store = vs[0].untyped_storage().data_ptr()
+        offs = [v.storage_offset() for v in vs]
+        lo = min(offs)
+        if all(v.untyped_storage().data_ptr() == store for v in vs) and sorted(offs) == list(range(lo, lo + len(vs))):
+            order = sorted(range(len(vs)), key=lambda i: offs[i])
+            return vs[0].as_strided((len(vs),), (1,), lo), [names[i] for i in order]
+    return pack_scalars(values), names
+
+
 def reduce_packed_async(keys, buf: torch.Tensor, op: str = "mean", group=None, force: bool = False) -> PendingScalars:
     """reduce_scalars_async for a vector made by pack_scalars: the all-reduce runs IN PLACE on `buf`, which the caller
     must leave alone until join() / result().  Nothing else is launched on the current stream, so a step that produces

@@ -301,7 +301,8 @@ class _ResidualLosses(torch.autograd.Function):
             return (None,) * (5 + len(fields))
         ghat, ctx.ghat = ctx.ghat, None      # handed out once; a second backward recomputes
         if ghat is not None and gs is None and ups[-1] is not None and all(u is None for u in ups[:-1]):
-            _BACKEND.rescale(ghat, ups[-1], ctx.assumed)
+            if ups[-1].data_ptr() != ctx.assumed.data_ptr():      # handed the assumed scalar itself: nothing to compare
+                _BACKEND.rescale(ghat, ups[-1], ctx.assumed)
             grads = ghat
         else:
             del ghat

@@ -153,6 +153,13 @@ class StencilPDELoss(nn.Module):
             return v.expand(B) if v.numel() == 1 else v
         return torch.full((B,), float(value), dtype=dt, device=ref.device)
 
+    def upstream_scalar(self, device) -> Tensor:
+        """The device scalar holding `upstream_hint`, the upstream gradient 'fused' mode assumes for `total`.  Passing this
+        very tensor to `total.backward(gradient=...)` tells the backward that the gradient computed in forward is the one
+        asked for, without a launch that compares the two values on the device."""
+        hint = float(self.upstream_hint)
+        return self._buf(("assumed", hint), lambda: torch.tensor(hint, dtype=torch.float32), torch.device(device))
+
     def _evaluate(self, fields: Sequence[Tensor], sparams: Sequence[Tensor] = (), aux: Sequence[Tensor] = (),
                   t_offset: Optional[Tensor] = None, reduction: str = "mean"):
         if reduction != "mean":

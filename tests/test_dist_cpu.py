@@ -179,3 +179,16 @@ def test_scale_accumulator_world2():
                 assert abs(x - y) <= 1e-6 * abs(y)
             assert abs(scalars[eq] - (sum(v * v for v in want[eq]) / 4) ** 0.5) <= 1e-5 * scalars[eq]
     assert ret[0][0] == ret[1][0]
+
+
+def test_pack_scalars_named_views_a_shared_buffer():
+    """Scalars that sit side by side in one buffer are packed without a copy (a view, in buffer order); others are stacked."""
+    base = torch.arange(5, dtype=torch.float32) * 1.5
+    vals = {"total": base[3], "a": base[1], "b": base[2]}
+    buf, names = pdist.pack_scalars_named(vals)
+    assert names == ["a", "b", "total"] and buf.data_ptr() == base[1].data_ptr() and buf.dtype == torch.float32
+    assert torch.equal(buf, base[1:4])
+    buf2, names2 = pdist.pack_scalars_named({"x": base[0], "y": base[3]})      # not adjacent: the general path
+    assert names2 == ["x", "y"] and buf2.dtype == torch.float64 and torch.equal(buf2, torch.tensor([0.0, 4.5], dtype=torch.float64))
+    buf3, names3 = pdist.pack_scalars_named({"x": torch.tensor(1.0), "y": torch.tensor(2.0)})
+    assert names3 == ["x", "y"] and torch.equal(buf3, torch.tensor([1.0, 2.0], dtype=torch.float64))
