@@ -732,6 +732,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 #pragma unroll
       for (int px = 0; px < W; ++px) {
         if (SPLIT_T && !NO_TIME) {      // frame n's gradient so far: its own frame's terms plus the share of frame n-1's residuals
+          aacc.px = px; aacc.i2 = pi2[q] + px;      // the coefficient may sit in an auxiliary field (1 / c(x)^2 of the Gaussian-speed wave equation)
 #pragma unroll
           for (int k = 0; k < P::NE; ++k) aacc.gm[k] = Gm1[q][px][k];
           float gt[P::NF];

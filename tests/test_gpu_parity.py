@@ -78,6 +78,17 @@ SIZED = [
     ("SwiftHohenberg3DPDELoss", dict(domain_extent=6.0, num_points=12, dt=0.1), (1, 4, 6, 10, 65), {}),
     ("Heat3DPDELoss", dict(nx=6, ny=10, nz=65, Lx=1.0, Ly=1.0, Lz=1.0, dt=0.01), (2, 4, 6, 10, 65), dict(alpha=(0.005, 0.05))),
     ("GrayScottPDELoss", dict(nx=24, ny=70, dx=0.1, dy=0.1, dt=10.0), (2, 5, 24, 70), {}),
+    ("Advection1DPDELoss", dict(dx=0.02, dt=0.01), (3, 6, 301), dict(a=(-1, 1))),
+    ("Heat1DPDELoss", dict(dx=0.02, dt=0.01), (3, 6, 301), dict(alpha=(0.005, 0.05))),
+    ("APEBenchBurgers1DPDELoss", dict(nx=301, Lx=1.0, dt=1.0), (2, 6, 301), {}),
+    ("KS1DPDELoss", dict(nx=301, Lx=1.0, dt=1.0), (2, 6, 301), {}),
+    ("KdV1DPDELoss", dict(nx=301, Lx=1.0, dt=1.0), (2, 6, 301), {}),
+    ("AdvDiff2DPDELoss", dict(dx=0.2, dy=0.3, dt=0.01, a=1.0, b=0.5, nu=0.05), (2, 5, 21, 70), {}),
+    ("AnisoDiff2DPDELoss", dict(dx=0.2, dy=0.3, dt=0.1), (2, 5, 21, 70), {}),
+    ("Wave2DPDELoss", dict(dx=0.2, dy=0.3, dt=0.01), (2, 5, 21, 70), dict(c=(0.5, 1.5))),
+    ("APEBenchBurgers2DPDELoss", dict(nx=70, ny=21, Lx=1.0, Ly=1.5, dt=1.0), (2, 5, 21, 70), {}),
+    ("ActiveMatterNPINNPDELoss", dict(nx=70, ny=21, Lx=2.0, Ly=3.0, dt=0.25, d_T=0.05), (2, 5, 21, 70), {}),
+    ("WaveGaussPDELoss", dict(nx=21, ny=70, Lx=1.0, Ly=1.0, dt=1.0 / 14, skip_boundary=1), (2, 5, 21, 70), dict(c=("field", 0.5, 1.5))),
 ]
 
 
@@ -96,6 +107,16 @@ def _quad_variant(entry):
 SIZED = SIZED + [_quad_variant(e) for e in SIZED]
 
 
+def _sized_extras(ps, shape, g):
+    """per-sample parameters (lo, hi) -> [B]; ("field", lo, hi) -> a time-independent field [B, *spatial]"""
+    out = {}
+    for k, r in ps.items():
+        size = (shape[0],) + tuple(shape[2:]) if r[0] == "field" else (shape[0],)
+        lo, hi = r[-2:]
+        out[k] = lo + (hi - lo) * torch.rand(size, generator=g)
+    return out
+
+
 @pytest.mark.parametrize("mode", ["auto", "stored", "fused"])
 @pytest.mark.parametrize("cls,kw,shape,ps", SIZED, ids=[f"{s[0]}-{s[2][-1]}" for s in SIZED])
 def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
@@ -106,7 +127,7 @@ def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
     fields = [torch.randn(shape, generator=g) * 0.5 for _ in range(nf)]
     if cls == "TurbulentRadiativePDELoss":
         fields[2] = fields[2].abs() + 0.5
-    extra = {k: lo + (hi - lo) * torch.rand(shape[0], generator=g) for k, (lo, hi) in ps.items()}
+    extra = _sized_extras(ps, shape, g)
     mod = getattr(PL, cls)(**kw).to(dev)
     mod.backward_mode = mode
     total, losses, grads = _run(mod, [f.to(dev) for f in fields], {k: v.to(dev) for k, v in extra.items()})

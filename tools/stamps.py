@@ -31,7 +31,7 @@ for it in range(3):
 d = dbg.cpu().numpy().reshape(16, 8, 20, 8).astype(np.float64)
 names = ["top->loads issued", "G stage", "barrier1", "gather", "barrier2", "stage LDS store (waits loads)", "grad stores + barrier3"]
 for blk in (0, 5):
-    for wv in (0, 3, 7):
+    for wv in (0, 1, 2, 3):
         x = d[blk, wv]
         if x[:, 0].max() == 0:
             continue
