@@ -89,6 +89,14 @@ SIZED = [
     ("APEBenchBurgers2DPDELoss", dict(nx=70, ny=21, Lx=1.0, Ly=1.5, dt=1.0), (2, 5, 21, 70), {}),
     ("ActiveMatterNPINNPDELoss", dict(nx=70, ny=21, Lx=2.0, Ly=3.0, dt=0.25, d_T=0.05), (2, 5, 21, 70), {}),
     ("WaveGaussPDELoss", dict(nx=21, ny=70, Lx=1.0, Ly=1.0, dt=1.0 / 14, skip_boundary=1), (2, 5, 21, 70), dict(c=("field", 0.5, 1.5))),
+    ("NSIncomPDELoss", dict(nx=40, ny=70, Lx=1.0, Ly=1.0, dt=0.005, nu=0.01, skip_bl=2), (2, 5, 40, 70),
+     dict(fx=("field", -1.0, 1.0), fy=("field", -1.0, 1.0))),
+    # 3-D grids of several chunks of planes (the last one short) and ragged (y, x) tiles
+    ("TaylorGreen3DPDELoss", dict(nx=37, ny=18, nz=42, Lx=2.0, Ly=1.0, Lz=3.0, dt=0.01), (1, 4, 37, 18, 42), dict(nu=(0.01, 0.1))),
+    ("APEBenchBurgers3DPDELoss", dict(nx=42, Lx=1.0, dt=1.0), (1, 4, 37, 18, 42), {}),
+    ("Heat3DPDELoss", dict(nx=37, ny=18, nz=42, Lx=1.0, Ly=1.0, Lz=1.0, dt=0.01), (2, 4, 37, 18, 42), dict(alpha=(0.005, 0.05))),
+    ("Advection3DPDELoss", dict(dx=0.1, dy=0.2, dz=0.3, dt=0.05), (1, 4, 37, 18, 42), dict(a=(-1, 1), b=(-1, 1), c=(-1, 1))),
+    ("SwiftHohenberg3DPDELoss", dict(domain_extent=6.0, num_points=42, dt=0.1), (1, 4, 37, 18, 42), {}),
 ]
 
 
@@ -139,6 +147,59 @@ def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
         assert abs(float(losses[k]) - float(ol[k])) <= TOL * abs(float(ol[k])) + 1e-30, k
     for gr, f in zip(grads, f64):
         assert rel_l2(gr.cpu().numpy(), f.grad.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("mode", ["auto", "stored", "fused"])
+@pytest.mark.parametrize("width", [70, 72])
+def test_per_t_scales_offsets_and_guards_at_tile_sizes(width, mode):
+    """Per-timestep scale tables with sample offsets (finetune/pde_loss_verified.py:854-901), non-unit weights and an
+    equation switched off by a zero weight, on grids that take the tiled kernels (the golden cases of these features are
+    a few points wide)."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    shape = (3, 7, 50, width)
+    fields = [torch.randn(shape, generator=g) * 0.5 for _ in range(3)]
+    nu = 0.01 + 0.09 * torch.rand(3, generator=g)
+    per_t = {k: 0.5 + torch.rand(9, generator=g) for k in ("continuity", "x_momentum", "y_momentum")}
+    base = dict(nx=width, ny=50, Lx=6.28, Ly=6.28, dt=0.01, eq_scales={"continuity": 0.5, "x_momentum": 2.0, "y_momentum": 3.0})
+    cases = [
+        (dict(base, eq_weights={"continuity": 1.0, "x_momentum": 0.7, "y_momentum": 1.1}, eq_scales_per_t=per_t),
+         dict(t_offset=torch.tensor([2, 7, 0]))),
+        (dict(base, eq_weights={"x_momentum": 0.7}, eq_scales_per_t=per_t), {}),
+        (dict(base, eq_weights={"y_momentum": 0.0}), {}),
+    ]
+    for kw, ex in cases:
+        mod = PL.TaylorGreen2DPDELoss(**kw).to(dev)
+        mod.backward_mode = mode
+        total, losses, grads = _run(mod, [f.to(dev) for f in fields], dict(nu=nu.to(dev), **{k: v.to(dev) for k, v in ex.items()}))
+        f64 = [f.double().requires_grad_(True) for f in fields]
+        ot, ol = OC.build("TaylorGreen2DPDELoss", **kw)(*f64, nu=nu.double(), **ex)
+        ot.backward()
+        assert abs(float(total) - float(ot)) <= TOL * abs(float(ot))
+        for k in ol:
+            assert abs(float(losses[k]) - float(ol[k])) <= TOL * abs(float(ol[k])) + 1e-30, k
+        for gr, f in zip(grads, f64):
+            assert rel_l2(gr.cpu().numpy(), f.grad.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 40, 72, 2), (2, 3, 37, 70, 2)])
+def test_ghost_burgers_at_tile_sizes(shape):
+    """burgers_pde_loss (finetune/pde_loss.py:87-216) on grids of several tiles: losses, residual fields and gradient
+    against the oracle"""
+    dev = _dev()
+    g = torch.Generator().manual_seed(37)
+    base = torch.randn(shape, generator=g) * 0.5
+    pred = base.to(dev).requires_grad_(True)
+    total, lu, lv, ru, rv = PL.burgers_pde_loss(pred, 0.03, dt=0.02, dx=0.11, dy=0.13)
+    (total + 0.5 * ru.sum()).backward()
+    p64 = base.double().requires_grad_(True)
+    ot, olu, olv, oru, orv = OC.burgers_pde_loss(p64, 0.03, dt=0.02, dx=0.11, dy=0.13)
+    (ot + 0.5 * oru.sum()).backward()
+    for a, b in ((total, ot), (lu, olu), (lv, olv)):
+        assert abs(float(a) - float(b)) <= TOL * abs(float(b))
+    assert rel_l2(ru.detach().cpu().numpy(), oru.detach().numpy()) <= TOL
+    assert rel_l2(rv.detach().cpu().numpy(), orv.detach().numpy()) <= TOL
+    assert rel_l2(pred.grad.cpu().numpy(), p64.grad.numpy()) <= TOL
 
 
 @pytest.mark.parametrize("cls,kw,shape,ps", [SIZED[1], SIZED[len(SIZED) // 2 + 1], SIZED[len(SIZED) // 2 + 2], SIZED[len(SIZED) // 2 + 3]],
