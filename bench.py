@@ -141,6 +141,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="fused", choices=["fused", "auto"],
                     help="loss module backward_mode: 'fused' = loss and gradient in one pass of the adjoint kernel (it recomputes "
                          "every residual anyway), 'auto' = forward kernel, then adjoint kernel")
+    ap.add_argument("--reduce-window", type=int, default=8,
+                    help="steps whose logging scalars share one all-reduce (dist.ScalarWindow); 1 = a collective every step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--dry", action="store_true",
                     help="rehearse the launcher, the rendezvous and the packed all-reduce without a GPU: no kernel runs, "
@@ -153,11 +155,16 @@ def dry_run(args, world, rank):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group(args.backend)
-    keys = ["total", "continuity", "x_momentum", "y_momentum"]
-    red = None
-    for i in range(args.warmup + args.steps):
-        buf = torch.tensor([1.0 + rank, 2.0, 3.0, 4.0], dtype=torch.float64)
-        red = pdist.reduce_packed_async(keys, buf).result()
+    win = pdist.ScalarWindow(["continuity", "x_momentum", "y_momentum", "total"], max(1, args.reduce_window), "cpu", dtype=torch.float64)
+    n = args.warmup + args.steps
+    for i in range(n):
+        win.before(i)
+        win.row(i).copy_(torch.tensor([2.0, 3.0, 4.0, 1.0 + rank + i], dtype=torch.float64))
+        win.after(i)
+    win.flush(n)
+    first, last = win.drain()[-1]
+    red = {k: v[-1] for k, v in last.items()}
+    assert first + len(last["total"]) == n and abs(float(red["total"]) - (n + (world - 1) / 2)) < 1e-9
     if world > 1:
         dist.barrier()
         n = torch.ones(1)
@@ -214,30 +221,35 @@ def main(argv=None):
 
     one = torch.ones((), device=dev)
 
-    def loss_step(k):
-        """forward + backward of the loss on input set k through the nn.Module API; gradients land in fields[i].grad"""
+    # The step's logging scalars (the per-equation losses and the total, which the reference reduces over the ranks every
+    # step) go straight from the reduction kernel into a row of a window buffer; one all-reduce per window of steps.
+    window = max(1, args.reduce_window)
+    win = pdist.ScalarWindow([*loss_fn.EQS, "total"], window, dev, force=distributed)
+
+    def loss_step(k, row=None):
+        """forward + backward of the loss on input set k through the nn.Module API; gradients land in fields[i].grad and
+        the loss scalars in `row`"""
         fields, nu = sets[k]
         for f in fields:
             f.grad = None
+        loss_fn.scalars_out = row
         total, losses = loss_fn(*fields, nu=nu)
         # the upstream gradient of the loss: the module's own resident scalar (upstream_hint = 1.0) instead of a fill launch
         # per step; handed the very tensor it assumed, the fused step knows without looking that no rescaling is due
         total.backward(gradient=loss_fn.upstream_scalar(dev) if args.mode == "fused" else one)
-        # the step's scalars as one vector, ready for the packed all-reduce: they already sit side by side in the buffer the
-        # reduction kernel wrote, so this is a view, not a launch (detached: nothing of the autograd graph outlives the step)
-        return pdist.pack_scalars_named({"total": total, **losses})
 
     for i in range(max(args.warmup, n_sets)):
-        buf, keys = loss_step(i % n_sets)
-        pdist.reduce_packed_async(keys, buf, force=distributed).result()
+        loss_step(i % n_sets)
+    if distributed:      # the first collective sets RCCL up: not inside the timed region
+        pdist.reduce_packed_async(["x"], torch.zeros(1, device=dev), force=True).result()
 
     # The step is launch-bound on the host (a few small launches plus autograd for ~0.15 ms of GPU work), so the
     # steady-state loop replays it as a HIP graph; every `probe`-th step of the timed region runs eagerly instead with
     # HIP events recorded right around the adjoint launch, which is where the roofline numbers come from.
-    # --no-graph runs every step eagerly.  One graph per input set (two for a single set), each leaving its packed
-    # scalars in its own buffer: the all-reduce of step i runs in place on its buffer, beside step i + 1, and is joined
-    # before that buffer is written again.
-    graphs, g_bufs = [], []
+    # --no-graph runs every step eagerly.  A graph is tied to its input set and to the window row its scalars land in: one
+    # graph per residue of the step index modulo lcm(2 * window, input sets).
+    n_graphs = math.lcm(2 * window, n_sets)
+    graphs = []
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -246,17 +258,20 @@ def main(argv=None):
                 loss_step(0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            for j in range(max(2, n_sets)):
+            # one memory pool for all graphs: they replay one after the other, in capture order, and the gradients of a
+            # capture are dropped when its input set is captured again, so the graphs share a few gradient buffers
+            # instead of holding one set each
+            pool = torch.cuda.graph_pool_handle()
+            for j in range(n_graphs):
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to query events
-                    gb, keys = loss_step(j % n_sets)
+                with torch.cuda.graph(gr, pool=pool, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to query events
+                    loss_step(j % n_sets, win.row(j))
                 gr.replay()
                 torch.cuda.synchronize()
                 graphs.append(gr)
-                g_bufs.append(gb)
         except Exception as e:      # capture unsupported here: eager loop
             print(f"bench: HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graphs, g_bufs = [], []
+            graphs = []
             torch.cuda.synchronize()
     graph = graphs[0] if graphs else None
     # an eager probe step costs more than a replayed one (the host cannot keep up), so only every 10th step is one
@@ -268,19 +283,18 @@ def main(argv=None):
     bwd_events, fwd_events = [], []
 
     def step(i):
+        win.before(i)      # opening a window: joins the all-reduce that still reads the rows this window overwrites
         if i % probe != probe - 1:
             if graph is None:      # --no-graph: an ordinary eager step through the C++ operator
-                buf, names = loss_step(i % n_sets)
-                return pdist.reduce_packed_async(names, buf, force=distributed)
-            j = i % len(graphs)
-            graphs[j].replay()
-            return pdist.reduce_packed_async(keys, g_bufs[j], force=distributed)
-        # fused mode has no forward launch to time, and with only the adjoint timer armed the step keeps the C++ operator
-        backend.backward_events, backend.forward_events = bwd_events, (None if args.mode == "fused" else fwd_events)
-        buf, names = loss_step(i % n_sets)
-        backend.backward_events = backend.forward_events = None
-        # the step's scalars: one packed all-reduce, started now and joined a step later so that it runs beside the next step
-        return pdist.reduce_packed_async(names, buf, force=distributed)
+                loss_step(i % n_sets, win.row(i))
+            else:
+                graphs[i % n_graphs].replay()
+        else:
+            # fused mode has no forward launch to time, and with only the adjoint timer armed the step keeps the C++ operator
+            backend.backward_events, backend.forward_events = bwd_events, (None if args.mode == "fused" else fwd_events)
+            loss_step(i % n_sets, win.row(i))
+            backend.backward_events = backend.forward_events = None
+        win.after(i)       # closing a window: starts its all-reduce, which runs beside the next window's steps
 
     backend.backward_event_pool, backend.forward_event_pool = pool(n_probe + 40), pool(n_probe + 40)
     # A few dozen 0.15 ms steps do not bring an idle GPU up to its working clocks (the same kernel measures 10 % slower in
@@ -292,7 +306,7 @@ def main(argv=None):
         while (time.perf_counter() - ts) * 1e3 < args.settle_ms:
             for j in range(16):
                 if graph is not None:
-                    graphs[(settle_steps + j) % len(graphs)].replay()
+                    graphs[(settle_steps + j) % n_graphs].replay()
                 else:
                     loss_step((settle_steps + j) % n_sets)
             settle_steps += 16
@@ -301,13 +315,10 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pending = None
     for i in range(args.steps):
-        nxt = step(i)
-        if pending is not None:
-            pending.join()
-        pending = nxt
-    red = pending.result()
+        step(i)
+    win.flush(args.steps)
+    red = {k: v[-1] for k, v in win.drain()[-1][1].items()}      # the last step's scalars, mean over the ranks
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -353,7 +364,10 @@ def main(argv=None):
             "config": {"workload": "Taylor-Green 2D incompressible NS residual fwd+bwd, B=16 per GPU, T=16, 256x256, 3 fields",
                        "parallelism": f"dp{world}", "points_per_step_per_gpu": pts_per_rank,
                        "launch": f"hip-graph replay, every {probe}th step eager with kernel events" if graph is not None else f"eager (C++ operator), every {probe}th step with kernel events",
-                       "backward_mode": args.mode, "input_sets": n_sets},
+                       "backward_mode": args.mode, "input_sets": n_sets,
+                       "logging": f"the step's loss scalars of {window} steps share one all-reduce (mean over the ranks), started "
+                                  f"when the window closes and joined a window later" if window > 1 else
+                                  "one all-reduce of the step's loss scalars per step, joined a step later"},
             "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step; HIP events recorded by "
                                                      "the library on the launch stream right before and after that launch" +
                                                      ("; in fused mode the kernel also sums the loss)" if args.mode == "fused" else ")"),

@@ -77,14 +77,16 @@ using torch::autograd::variable_list;
 struct ResidualLosses : public torch::autograd::Function<ResidualLosses> {
   // outputs: totals[0..n_eqs] as 0-dim tensors, then sums[B, n_eqs]
   static variable_list forward(AutogradContext* ctx, at::TensorList fields, at::TensorList aux, at::TensorList sparams,
-                               const at::Tensor& weights, const std::optional<at::Tensor>& assumed, int64_t cfg_handle) {
+                               const at::Tensor& weights, const std::optional<at::Tensor>& assumed, int64_t cfg_handle,
+                               int64_t totals_handle) {
     const Config& c = *reinterpret_cast<const Config*>(cfg_handle);
     const at::Tensor& f0 = fields[0];
     const c10::hip::HIPStream stream = c10::hip::getCurrentHIPStream(f0.device().index());
     c10::hip::HIPGuard guard(f0.device().index());
     const int ne = c.n_eqs, B = c.prob.batch;
     at::Tensor sums = at::empty({B, ne}, f0.options().dtype(at::kDouble));
-    at::Tensor totals = at::empty({ne + 1}, f0.options());
+    // the caller's vector when it gave one (not an input of the node: the returned scalars are plain views of it)
+    at::Tensor totals = totals_handle ? *reinterpret_cast<const at::Tensor*>(totals_handle) : at::empty({ne + 1}, f0.options());
     const size_t ws_bytes = abi.workspace_bytes(&c.prob);
     at::Tensor& ws = workspace(f0.device(), stream.stream(), ws_bytes);
     Ptrs<PDE_AMD_MAX_FIELDS> pf(fields);
@@ -144,7 +146,7 @@ struct ResidualLosses : public torch::autograd::Function<ResidualLosses> {
     const auto counts = ctx->saved_data["counts"].toIntVector();
     const int nf = (int)counts[0], na = (int)counts[1], ns = (int)counts[2], ne = c.n_eqs;
     const variable_list saved = ctx->get_saved_variables();
-    variable_list result((size_t)(nf + na + ns + 3));      // undefined = no gradient
+    variable_list result((size_t)(nf + na + ns + 4));      // undefined = no gradient
     bool any_tot = false, only_last = true;
     for (int k = 0; k <= ne; ++k) {
       if (gouts[k].defined()) {
@@ -207,10 +209,12 @@ struct ResidualLosses : public torch::autograd::Function<ResidualLosses> {
 };
 
 // fields: tensors of one shape on one HIP device (converted to contiguous fp32 when they are not); consts/lo/hi as in
-// pde_amd_problem; mode 0 recompute, 1 stored, 2 fused (then `assumed` is the device scalar of the upstream value to assume).
+// pde_amd_problem; mode 0 recompute, 1 stored, 2 fused (then `assumed` is the device scalar of the upstream value to assume);
+// totals_out: where the n_eqs + 1 loss scalars are written instead of a fresh vector (the returned scalars are views of it).
 std::vector<at::Tensor> residual_losses(at::TensorList fields, at::TensorList aux, at::TensorList sparams, const at::Tensor& weights,
                                         int64_t pde_id, c10::ArrayRef<double> consts, at::IntArrayRef lo, at::IntArrayRef hi,
-                                        int64_t n_eqs, int64_t t_lo, int64_t t_hi, int64_t mode, const std::optional<at::Tensor>& assumed) {
+                                        int64_t n_eqs, int64_t t_lo, int64_t t_hi, int64_t mode, const std::optional<at::Tensor>& assumed,
+                                        const std::optional<at::Tensor>& totals_out) {
   TORCH_CHECK(abi.forward != nullptr, "pde_amd: the kernel library is not bound (pde_amd_torch_bind)");
   TORCH_CHECK(!fields.empty() && fields.size() <= PDE_AMD_MAX_FIELDS && fields[0].dim() >= 3 && fields[0].dim() <= 5, "pde_amd: bad fields");
   TORCH_CHECK(consts.size() <= PDE_AMD_MAX_CONSTS && lo.size() == 3 && hi.size() == 3 && n_eqs <= PDE_AMD_MAX_EQS, "pde_amd: bad problem");
@@ -257,15 +261,20 @@ std::vector<at::Tensor> residual_losses(at::TensorList fields, at::TensorList au
     sp.push_back(prepared(p, dev));
   }
   TORCH_CHECK(weights.numel() == n_eqs * (int64_t)c.t_res, "pde_amd: weights must be [n_eqs, T_res]");
+  const bool given = totals_out.has_value() && totals_out->defined();
+  if (given)
+    TORCH_CHECK(totals_out->scalar_type() == at::kFloat && totals_out->device() == dev && totals_out->dim() == 1 &&
+                    totals_out->numel() == n_eqs + 1 && totals_out->is_contiguous() && !totals_out->requires_grad(),
+                "pde_amd: totals_out must be a contiguous fp32 vector of n_eqs + 1 = ", n_eqs + 1, " elements on the fields' device");
   return ResidualLosses::apply(at::TensorList(fs), at::TensorList(ax), at::TensorList(sp), prepared(weights, dev), assumed,
-                               reinterpret_cast<int64_t>(&c));
+                               reinterpret_cast<int64_t>(&c), given ? reinterpret_cast<int64_t>(&*totals_out) : (int64_t)0);
 }
 
 }  // namespace
 
 TORCH_LIBRARY(pde_amd, m) {
   m.def("residual_losses(Tensor[] fields, Tensor[] aux, Tensor[] sparams, Tensor weights, int pde_id, float[] consts, int[] lo, "
-        "int[] hi, int n_eqs, int t_lo, int t_hi, int mode, Tensor? assumed) -> Tensor[]",
+        "int[] hi, int n_eqs, int t_lo, int t_hi, int mode, Tensor? assumed, Tensor? totals_out=None) -> Tensor[]",
         &residual_losses);
 }
 

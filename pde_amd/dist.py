@@ -8,7 +8,7 @@ travel in one buffer through one RCCL all-reduce.
 """
 from __future__ import annotations
 
-from typing import Dict, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -93,6 +93,77 @@ def reduce_packed_async(keys, buf: torch.Tensor, op: str = "mean", group=None, f
         return PendingScalars(keys, buf, None, 1.0)
     work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return PendingScalars(keys, buf, work, 1.0 / dist.get_world_size(group) if op == "mean" else 1.0)
+
+
+class ScalarWindow:
+    """The scalars of `steps` consecutive steps in one buffer, reduced over the ranks with ONE all-reduce per window.
+
+    The reference reduces its logging scalars with a collective each, every step (accelerator.reduce on bc_loss and pde_loss,
+    finetune/train_taylor_green_2d_lora_v3.py:522-523).  A 0.13 ms step cannot afford even one: on MI355X the stream
+    hand-over around a small asynchronous all-reduce takes about 21 us of the step's timeline, whatever the message size.
+    Here step i leaves its scalars in `row(i)` (hand that row to the loss module as `scalars_out`, or copy into it), and
+    `after(i)`, called once step i is enqueued, starts the all-reduce of a window when step i completes it; the collective
+    runs in place, beside the steps of the next window.  Two windows alternate, and `before(i)`, called ahead of step i,
+    joins the collective that still reads the rows the coming window overwrites and keeps its result: `drain()` returns
+    the windows finished since the last call, oldest first, as (first_step, {name: tensor[steps of that window]}).
+    `flush()` reduces a partly filled last window.  A single process runs no collective (force=True does, for rehearsal).
+    """
+
+    def __init__(self, names: Sequence[str], steps: int, device, dtype=torch.float32, op: str = "mean", group=None, force: bool = False):
+        if op not in ("mean", "sum"):
+            raise ValueError("op must be 'mean' or 'sum'")
+        if steps < 1 or not names:
+            raise ValueError("ScalarWindow needs at least one name and one step per window")
+        self.names, self.steps, self.op, self.group, self.force = list(names), int(steps), op, group, force
+        self.buf = torch.zeros((2, self.steps, len(self.names)), dtype=dtype, device=device)
+        self._pending: List[Optional[tuple]] = [None, None]      # per half: (first step, rows filled, handle)
+        self._done: List[tuple] = []
+        self._filled = 0
+
+    def row(self, i: int) -> torch.Tensor:
+        """Where step i leaves its scalars: a contiguous vector of len(names) elements."""
+        return self.buf[(i // self.steps) % 2, i % self.steps]
+
+    def before(self, i: int) -> None:
+        """Ahead of step i: when it opens a window, join the collective that still owns the window's rows."""
+        if i % self.steps == 0:
+            self._finish((i // self.steps) % 2)
+
+    def after(self, i: int) -> None:
+        """Once step i is enqueued: when it completes a window, start that window's all-reduce."""
+        self._filled = i % self.steps + 1
+        if self._filled == self.steps:
+            self._start(i - self.steps + 1, self.steps)
+            self._filled = 0
+
+    def flush(self, next_step: int) -> None:
+        """Reduce the rows of an unfinished window (next_step = the index the next step would have had) and join everything."""
+        if self._filled:
+            self._start(next_step - self._filled, self._filled)
+            self._filled = 0
+        for h in ((next_step // self.steps + 1) % 2, (next_step // self.steps) % 2):      # older window first
+            self._finish(h)
+
+    def drain(self) -> List[tuple]:
+        out, self._done = self._done, []
+        return out
+
+    def _start(self, first: int, rows: int) -> None:
+        h = (first // self.steps) % 2
+        self._finish(h)
+        vec = self.buf[h, :rows].reshape(-1)      # contiguous: a view
+        handle = reduce_packed_async(range(vec.numel()), vec, self.op, self.group, self.force)
+        self._pending[h] = (first, rows, handle)
+
+    def _finish(self, h: int) -> None:
+        if self._pending[h] is None:
+            return
+        first, rows, handle = self._pending[h]
+        self._pending[h] = None
+        handle.join()
+        vals = self.buf[h, :rows]
+        vals = vals * handle._scale if handle._scale != 1.0 else vals.clone()      # the rows are about to be overwritten
+        self._done.append((first, {n: vals[:, j] for j, n in enumerate(self.names)}))
 
 
 def reduce_scalars(values: Dict[str, torch.Tensor], op: str = "mean", group=None) -> Dict[str, torch.Tensor]:

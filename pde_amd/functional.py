@@ -12,6 +12,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -125,7 +126,7 @@ class HipBackend:
         TR = max(T - s.tlo - s.thi, 0)
         ne = len(s.eqs)
         sums = torch.empty((B, ne), dtype=torch.float64, device=f0.device)
-        totals = torch.empty((ne + 1,), dtype=torch.float32, device=f0.device)
+        totals = new_totals(ne, f0.device)
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
         resid = None
@@ -202,7 +203,7 @@ class HipBackend:
         cp = prob.c_struct(f0.shape)
         ne = len(s.eqs)
         sums = torch.empty((f0.shape[0], ne), dtype=torch.float64, device=f0.device)
-        totals = torch.empty((ne + 1,), dtype=torch.float32, device=f0.device)
+        totals = new_totals(ne, f0.device)
         grads = [torch.empty_like(f) for f in fields]
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
@@ -234,6 +235,39 @@ _HOST = os.environ.get("PDE_AMD_HOST", "op")
 if _HOST not in ("op", "ctypes"):
     raise ValueError(f"PDE_AMD_HOST must be 'op' or 'ctypes', got {_HOST!r}")
 _MODES = {"recompute": 0, "stored": 1, "fused": 2}
+
+
+_DEST = threading.local()
+
+
+class totals_into:
+    """Context: the residual-loss calls inside write their n_eqs + 1 loss scalars into `vec` (a contiguous fp32 vector on
+    the fields' device) instead of a fresh tensor, and the scalars they return are views of it.  For callers that collect
+    the scalars of many steps in one buffer (dist.ScalarWindow) without a copy launch per step.  None: no effect."""
+
+    def __init__(self, vec: Optional[torch.Tensor]):
+        self.vec = vec
+
+    def __enter__(self):
+        self.old = getattr(_DEST, "vec", None)
+        _DEST.vec = self.vec
+        return self.vec
+
+    def __exit__(self, *exc):
+        _DEST.vec = self.old
+        return False
+
+
+def new_totals(ne: int, device, dtype=torch.float32) -> torch.Tensor:
+    """The vector a residual-loss call writes its scalars to: the one named by an enclosing totals_into, else a fresh one."""
+    vec = getattr(_DEST, "vec", None)
+    if vec is None or dtype is not torch.float32:
+        return torch.empty((ne + 1,), dtype=dtype, device=device)
+    if vec.dtype is not torch.float32 or vec.dim() != 1 or vec.numel() != ne + 1 or not vec.is_contiguous() or vec.device != device \
+            or vec.requires_grad:
+        raise ValueError(f"totals_into: need a contiguous fp32 vector of {ne + 1} elements on {device} that requires no gradient, "
+                         f"got {tuple(vec.shape)} {vec.dtype} on {vec.device}")
+    return vec
 
 
 def set_backend(b):
@@ -436,7 +470,7 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
         mode = resolve_mode(mode, prob.spec)
         ev = be._arm_adjoint_timer() if fused_timed else None
         try:
-            out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed)
+            out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed, getattr(_DEST, "vec", None))
         finally:
             be._disarm_adjoint_timer(ev)
         return out[:-1], out[-1]

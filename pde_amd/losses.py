@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functional import StencilProblem, residual_fields, residual_losses, residual_losses_and_fields
+from .functional import StencilProblem, residual_fields, residual_losses, residual_losses_and_fields, totals_into
 from .stencil.specs import SPECS
 
 Tensor = torch.Tensor
@@ -40,6 +40,11 @@ class StencilPDELoss(nn.Module):
     # then delivers another upstream value (lambda_pde, a loss scaler) the gradient is rescaled on the device, one more
     # pass over it: set upstream_hint to the factor the training loop applies to `total`.  No host synchronisation.
     upstream_hint = 1.0
+    # A contiguous fp32 vector of len(EQS) + 1 elements on the fields' device, or None.  When set, the mean-reduction forward
+    # writes [loss of every equation..., their sum] into it and the returned scalars are views of it: a training loop that
+    # logs through dist.ScalarWindow hands a row of the window here and pays no copy launch per step.  Entries of skipped
+    # equations hold the kernel's value (0), and the total is the kernel's sum over the kept equations.
+    scalars_out: Optional[Tensor] = None
 
     def _init_common(self, default_scales, eq_scales, eq_weights, eq_scales_per_t, per_t_supported=True):
         self.eq_scales = {**default_scales, **(eq_scales or {})}
@@ -184,7 +189,8 @@ class StencilPDELoss(nn.Module):
         if mode == "fused":
             hint = float(self.upstream_hint)
             mode = ("fused", self._buf(("assumed", hint), lambda: torch.tensor(hint, dtype=torch.float32), f0.device))
-        totals, sums = residual_losses(prob, fields, wt, sparams, aux, mode=mode)
+        with totals_into(self.scalars_out):
+            totals, sums = residual_losses(prob, fields, wt, sparams, aux, mode=mode)
         self.last_per_sample = sums.detach()        # [B, n_eqs] fp64 diagnostic: each sample's share of every loss
         losses: Dict[str, Tensor] = {}
         all_kept = not any(skipped) and n_sites > 0

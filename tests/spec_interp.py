@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from pde_amd import functional as PF
 from pde_amd.stencil import expr as X
 from pde_amd.stencil.specs import SPECS
 
@@ -146,7 +147,8 @@ class InterpBackend:
         tot = np.float32(0.0)
         for v in per_eq:
             tot = np.float32(tot + v)
-        totals = torch.tensor(np.concatenate([per_eq, [tot]]), dtype=torch.float32, device=dev)
+        totals = PF.new_totals(len(per_eq), dev)      # the caller's vector inside functional.totals_into
+        totals.copy_(torch.tensor(np.concatenate([per_eq, [tot]]), dtype=torch.float32, device=dev))
         return totals, torch.tensor(sums, dtype=torch.float64, device=dev), resid
 
     def forward_f64(self, prob, fields, aux, sparams, weights):

@@ -36,4 +36,4 @@ def test_two_rank_gloo_dry_run():
     assert len(lines) == 1                                       # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["dry"] is True
-    assert out["loss"] == 1.5                                    # mean over the two ranks of 1 + rank
+    assert out["loss"] == 4.5                                    # last of the 4 steps: mean over the two ranks of 1 + rank + 3

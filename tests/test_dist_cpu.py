@@ -77,6 +77,32 @@ def _case_sharded_loss(rank, world):
     return float(full), float(red["total"]), (a, b)
 
 
+def _case_scalar_window(rank, world):
+    """11 steps through windows of 4: every step's scalars come back as the mean over the ranks, in step order"""
+    import pde_amd
+    from pde_amd import functional as PF
+    from tests.spec_interp import InterpBackend
+    PF.set_backend(InterpBackend())
+    win = pdist.ScalarWindow(["continuity", "x_momentum", "y_momentum", "total"], steps=4, device="cpu")
+    g = torch.Generator().manual_seed(5 + rank)
+    fn = pde_amd.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01)
+    mine = []
+    for i in range(11):
+        fields = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(3)]
+        win.before(i)
+        fn.scalars_out = win.row(i)
+        total, losses = fn(*fields, nu=torch.tensor([0.02]))
+        assert total.data_ptr() == win.row(i)[3].data_ptr()      # a view of the window's row: no copy
+        mine.append([float(losses[k]) for k in ("continuity", "x_momentum", "y_momentum")] + [float(total)])
+        win.after(i)
+    win.flush(11)
+    got = {}
+    for first, vals in win.drain():
+        for j in range(len(vals["total"])):
+            got[first + j] = [float(vals[k][j]) for k in ("continuity", "x_momentum", "y_momentum", "total")]
+    return mine, got
+
+
 def _case_accumulator(rank, world):
     from pde_amd import metrics as PM
     from pde_amd import reductions as R
@@ -179,6 +205,35 @@ def test_scale_accumulator_world2():
                 assert abs(x - y) <= 1e-6 * abs(y)
             assert abs(scalars[eq] - (sum(v * v for v in want[eq]) / 4) ** 0.5) <= 1e-5 * scalars[eq]
     assert ret[0][0] == ret[1][0]
+
+
+def test_scalar_window_world2():
+    _free_port.port = _free_port()
+    ret = _run(_case_scalar_window)
+    assert sorted(ret[0][1]) == sorted(ret[1][1]) == list(range(11))
+    for i in range(11):
+        want = [(a + b) / 2 for a, b in zip(ret[0][0][i], ret[1][0][i])]
+        for r in (0, 1):
+            for x, y in zip(ret[r][1][i], want):
+                assert abs(x - y) <= 1e-6 * abs(y)
+
+
+def test_scalar_window_single_process():
+    """no process group: the window hands every step's own scalars back, whole windows and the short last one"""
+    win = pdist.ScalarWindow(["a", "b"], steps=3, device="cpu", op="sum")
+    for i in range(7):
+        win.before(i)
+        win.row(i).copy_(torch.tensor([float(i), 10.0 * i]))
+        win.after(i)
+    first = win.drain()                  # windows 0 is joined when window 2 opens (step 6)
+    assert [f for f, _ in first] == [0]
+    win.flush(7)
+    done = first + win.drain()
+    assert [f for f, _ in done] == [0, 3, 6]
+    assert torch.cat([v["a"] for _, v in done]).tolist() == [float(i) for i in range(7)]
+    assert torch.cat([v["b"] for _, v in done]).tolist() == [10.0 * i for i in range(7)]
+    with pytest.raises(ValueError):
+        pdist.ScalarWindow([], steps=3, device="cpu")
 
 
 def test_pack_scalars_named_views_a_shared_buffer():

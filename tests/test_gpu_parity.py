@@ -549,3 +549,35 @@ def test_ghost_burgers_residuals_are_in_graph():
         ot, olu, olv, oru, orv = OC.burgers_pde_loss(p64, 0.03, dt=0.02, dx=0.11, dy=0.13)
         use(ot, olu, oru, orv, wgt.double()).backward()
         assert rel_l2(pred.grad.cpu().numpy(), p64.grad.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("host", ["op", "ctypes"])
+def test_scalars_out_on_the_device(host):
+    """`scalars_out` through the C++ operator and through the Python function: the losses land in the caller's vector
+    (a row of a larger buffer), the returned scalars are views of it, values and gradients as without it."""
+    from pde_amd import functional as PF
+    dev = _dev()
+    g = torch.Generator().manual_seed(19)
+    fields = [torch.randn(2, 5, 20, 72, generator=g).to(dev) for _ in range(3)]
+    nu = torch.tensor([0.02, 0.05], device=dev)
+    old, PF._HOST = PF._HOST, host
+    try:
+        for mode in ("auto", "stored", "fused"):
+            ref = PL.TaylorGreen2DPDELoss(nx=72, ny=20, dt=0.01).to(dev)
+            ref.backward_mode = mode
+            t0, l0, g0 = _run(ref, fields, dict(nu=nu))
+            mod = PL.TaylorGreen2DPDELoss(nx=72, ny=20, dt=0.01).to(dev)
+            mod.backward_mode = mode
+            window = torch.full((3, 4), -1.0, device=dev)
+            mod.scalars_out = window[1]
+            t1, l1, g1 = _run(mod, fields, dict(nu=nu))
+            assert t1.data_ptr() == window[1, 3].data_ptr() and l1["x_momentum"].data_ptr() == window[1, 1].data_ptr()
+            assert window[1].tolist() == [float(l0["continuity"]), float(l0["x_momentum"]), float(l0["y_momentum"]), float(t0)]
+            assert window[0].tolist() == [-1.0] * 4 and window[2].tolist() == [-1.0] * 4
+            for a, b in zip(g0, g1):
+                assert torch.equal(a, b)
+        mod.scalars_out = torch.zeros(3, device=dev)
+        with pytest.raises((ValueError, RuntimeError)):
+            mod(*fields, nu=nu)
+    finally:
+        PF._HOST = old

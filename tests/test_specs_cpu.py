@@ -197,3 +197,28 @@ def test_flow_mixing_v2_golden():
         assert close(x, z[f"f64_{n}"], 2e-5), n
     for n, x in zip(names, ins):
         assert rel_l2(x.grad.cpu().numpy(), z[f"f64_grad_{n}"]) <= 2e-5, n
+
+
+def test_scalars_out_receives_the_losses():
+    """`scalars_out`: the losses land in the caller's vector and the returned scalars are views of it, same values and
+    gradients as without; a vector of the wrong shape or dtype is refused."""
+    g = torch.Generator().manual_seed(17)
+    fields = [torch.randn(2, 5, 8, 8, generator=g) for _ in range(3)]
+    nu = torch.tensor([0.02, 0.05])
+    for mode in ("auto", "stored", "fused"):
+        ref = PL.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01)
+        ref.backward_mode = mode
+        t0, l0, g0 = _run(ref, fields, dict(nu=nu))
+        mod = PL.TaylorGreen2DPDELoss(nx=8, ny=8, dt=0.01)
+        mod.backward_mode = mode
+        vec = torch.full((4,), -1.0)
+        mod.scalars_out = vec
+        t1, l1, g1 = _run(mod, fields, dict(nu=nu))
+        assert t1.data_ptr() == vec[3].data_ptr() and l1["continuity"].data_ptr() == vec[0].data_ptr()
+        assert vec.tolist() == [float(l0["continuity"]), float(l0["x_momentum"]), float(l0["y_momentum"]), float(t0)]
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)
+    for bad in (torch.zeros(3), torch.zeros(4, dtype=torch.float64), torch.zeros(8)[::2]):
+        mod.scalars_out = bad
+        with pytest.raises(ValueError):
+            mod(*fields, nu=nu)
