@@ -63,7 +63,10 @@ __global__ __launch_bounds__(1024) void pair_stats_kernel(const float* __restric
   for (; i + (long)(PS_UNROLL - 1) * NT < last; i += (long)PS_UNROLL * NT) {
     float pv[PS_UNROLL], gv[PS_UNROLL];
 #pragma unroll
-    for (int u = 0; u < PS_UNROLL; ++u) { pv[u] = p[i + (long)u * NT]; gv[u] = q[i + (long)u * NT]; }
+    for (int u = 0; u < PS_UNROLL; ++u) {      // both tensors are read once: streaming loads
+      pv[u] = __builtin_nontemporal_load(p + i + (long)u * NT);
+      gv[u] = __builtin_nontemporal_load(q + i + (long)u * NT);
+    }
     if (affine) {
 #pragma unroll
       for (int u = 0; u < PS_UNROLL; ++u) pv[u] = __fadd_rn(__fmul_rn(pv[u], sc), sh);
@@ -368,7 +371,9 @@ __global__ __launch_bounds__(TILE_PTS) void gather_tile_kernel(const GatherArgs 
     const unsigned np = min((unsigned)TILE_PTS, (unsigned)a.S - p0);
     const float* src = (t == 0 ? a.input + (b * a.T_in) * a.S * C : a.output + (b * a.T_out + (t - 1)) * a.S * C) + (long)p0 * C;
     const unsigned n4 = np * C / 4;
-    for (unsigned i = tid; i < n4; i += TILE_PTS) reinterpret_cast<f4*>(tile)[i] = reinterpret_cast<const f4*>(src)[i];
+    // read once and never again: a streaming load, so that the 18-channel tensor does not push the gathered fields (which
+    // the residual kernels read next) out of the caches
+    for (unsigned i = tid; i < n4; i += TILE_PTS) reinterpret_cast<f4*>(tile)[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src) + i);
     __syncthreads();
     if (tid < np) {
       const long dst = frame * a.S + field_site(a, p0 + tid);
@@ -446,8 +451,8 @@ __global__ __launch_bounds__(TILE_PTS) void stats_gather_tile_kernel(const float
     const long src = (((long)g * gs.frames + t) * gs.S + p0) * C;
     const unsigned n4 = np * C / 4;
     for (unsigned i = tid; i < n4; i += TILE_PTS) {
-      reinterpret_cast<f4*>(tp)[i] = reinterpret_cast<const f4*>(pred + src)[i];
-      reinterpret_cast<f4*>(tq)[i] = reinterpret_cast<const f4*>(target + src)[i];
+      reinterpret_cast<f4*>(tp)[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(pred + src) + i);      // streamed once
+      reinterpret_cast<f4*>(tq)[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(target + src) + i);
     }
     __syncthreads();
     if (tid < np) {
