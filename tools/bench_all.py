@@ -1,4 +1,4 @@
-"""Forward+backward timing of every residual loss at the survey's configurations (HIP events; algorithmic bytes
+"""Forward+backward timing of every residual loss at the reference's benchmark configurations (HIP events; algorithmic bytes
 12 * E_in per step).  Prints one line per case; --json writes the table."""
 import inspect
 import json
