@@ -1,0 +1,24 @@
+"""Every symbolic spec's HIP kernels against the NumPy interpreter of the same spec on seeded random problems: ragged and
+quad-width extents, clips of 1 to 17 residual frames, random lattice crops, weights, constants and per-sample parameters,
+in every backward mode the PDE supports (tools/fuzz_parity.py runs longer campaigns of the same cases)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pde_amd import functional as PF
+from pde_amd.stencil.specs import SPECS
+from tests.spec_interp import InterpBackend
+from tools.fuzz_parity import one_case
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+def test_random_problems_match_the_interpreter(name):
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + list(SPECS).index(name))
+    hip, interp = PF.get_backend(), InterpBackend()
+    for c in range(4):
+        desc, bad = one_case(name, rng, dev, hip, interp, quad=(c % 2 == 1))
+        assert not bad, (desc, bad)
