@@ -22,3 +22,16 @@ def test_random_problems_match_the_interpreter(name):
     for c in range(4):
         desc, bad = one_case(name, rng, dev, hip, interp, quad=(c % 2 == 1))
         assert not bad, (desc, bad)
+
+
+def test_random_glue_problems_match_the_oracle():
+    """boundary variants, patch seams + no-slip walls, the statistics reductions and the channel gather on seeded random
+    shapes, masks and strip widths, values and gradients, against the CPU oracle (tools/fuzz_glue.py)"""
+    from tools import fuzz_glue as FG
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    for _ in range(12):
+        for fn in (FG.boundary_case, FG.seam_case, FG.stats_case, FG.gather_case):
+            desc, err = fn(rng, dev)
+            assert np.isfinite(err) and err <= FG.TOL, (desc, err)
