@@ -1,7 +1,7 @@
-"""Diagnostic: the boundary-term, seam, statistics and gather kernels against the CPU oracle on random shapes, channel masks
+"""Test infrastructure: the boundary-term, seam, statistics and gather kernels against the CPU oracle on random shapes, channel masks
 and strip widths (values and gradients).  Prints one line per case; exit status 1 when anything differs.
 
-    python tools/fuzz_glue.py [--cases N] [--seed S]
+    python -m tests.fuzz_glue [--cases N] [--seed S]
 """
 import argparse
 import os

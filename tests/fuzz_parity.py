@@ -1,8 +1,8 @@
-"""Diagnostic: the HIP kernels of every symbolic spec against the NumPy interpreter of the same spec on random shapes
+"""Test infrastructure: the HIP kernels of every symbolic spec against the NumPy interpreter of the same spec on random shapes
 (ragged and tile-sized extents, short and long clips, random lattice crops, weights and constants), in every backward
 mode the PDE supports.  Prints one line per case and the failures at the end; exit status 1 when anything differs.
 
-    python tools/fuzz_parity.py [--cases N per spec] [--seed S] [--only spec ...]
+    python -m tests.fuzz_parity [--cases N per spec] [--seed S] [--only spec ...]
 """
 import argparse
 import os
