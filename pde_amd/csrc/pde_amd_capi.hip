@@ -150,6 +150,16 @@ struct Ops {
     return PDE_AMD_OK;
   }
 
+  // The marching adjoint's mask-free instantiation applies when no quad of any workgroup can leave the lattice: no crop,
+  // a whole number of tiles along every axis, and periodic wrap-around wherever a tile has a halo.
+  static bool full_grid(const pde_amd_problem* p) {
+    using C = QuadCfg<P, P::QWB>;
+    for (int a = 0; a < 3; ++a)
+      if (p->lo[a] != 0 || p->hi[a] != 0) return false;
+    if (p->n[0] % P::QB0 != 0 || p->n[1] % P::QB1 != 0 || p->n[2] % P::QB2 != 0) return false;
+    return (P::PER0 || C::HB0 == 0) && (P::PER1 || C::HB1 == 0) && (P::PER2 || C::HB2 == 0) && P::NA == 0;
+  }
+
   static long fwd_tiles(const pde_amd_problem* p) {
     return (long)cdiv(p->n[0], P::FT0) * cdiv(p->n[1], P::FT1) * cdiv(p->n[2], P::FT2);
   }
@@ -361,7 +371,10 @@ struct Ops {
         if (nwg < (1L << 31) && (size_t)nwg * P::NE * sizeof(double) <= ws_bytes_given) {
           {
             AdjointTimer timer(stream);
-            hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
+            if (full_grid(p))
+              hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
+            else
+              hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
           }
           reduce_partials(a.partial, sums, totals, items, p->batch, stream);
           fused = true;
@@ -453,7 +466,10 @@ struct Ops {
         constexpr int dyn_lds = 0;
 #endif
         AdjointTimer timer(stream);
-        hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
+        if (full_grid(p))
+          hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, false, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
+        else
+          hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
       }
     } else {
       if constexpr (BwdMarchFits<P>::value) {

@@ -120,6 +120,8 @@ struct StagerQ {
 #pragma unroll
     for (int j = 0; j < EPT; ++j) asm volatile("" ::"v"(v[j]));
   }
+  // ALLPLAIN: the caller knows that no element of any lane lies outside the domain (periodic axes)
+  template <bool ALLPLAIN = false>
   __device__ __forceinline__ void store(const fv (&v)[EPT], float* __restrict__ tile) const {
     touch(v);      // elements past the tile end are fetched but not stored
 #pragma unroll
@@ -128,7 +130,7 @@ struct StagerQ {
       const fv z = vec_zero<W>();
       if (EPT * NT == NQ || i < NQ) {
         // wall-side quads read 0; the select is skipped (a real branch) where no lane of the wave needs it
-        if (plain[j]) *reinterpret_cast<fv*>(tile + W * i) = v[j];
+        if (ALLPLAIN || plain[j]) *reinterpret_cast<fv*>(tile + W * i) = v[j];
         else *reinterpret_cast<fv*>(tile + W * i) = (off[j] & OUTSIDE) ? z : v[j];
       }
     }
@@ -423,7 +425,9 @@ struct MarchAdjAccQ : SiteBase<P> {
 
 // WITH_LOSS: the kernel also leaves the forward's partial sums (sum of weight * R^2 over the tile, frames of this
 // chunk) in a.partial: the residuals are recomputed here anyway, so a training step needs no separate forward launch.
-template <class P, int W, bool WITH_LOSS = false>
+// FULL: the host has checked that the grid is periodic along every axis with a halo, a whole number of tiles, and not
+// cropped: every quad of every lane lies on the lattice, so the kernel carries no masks and no branches around them.
+template <class P, int W, bool WITH_LOSS = false, bool FULL = false>
 __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bwd_march_q_kernel(const Args a) {
   using C = QuadCfg<P, W>;
   using fv = typename VecOf<W>::type;
@@ -454,6 +458,23 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   constexpr bool VGU = true;
 #endif
   constexpr bool ALT = RPT >= 2 && NT % 128 == 0 && NRQ - (RPT - 1) * NT <= NT / 2;
+  // Own quad first: when every lane owns exactly one output quad and the rest of the region (the rim) fits one more
+  // round, round 0 evaluates the residuals at the lane's own output quad and the last round covers the rim.  The lane's
+  // own scaled residuals then never come back from LDS, and only rim quads are excluded from the loss sums.
+#ifdef PDE_AMD_NO_OWN_FIRST
+  constexpr bool OWN = false;
+#else
+  constexpr bool OWN = QPT == 1 && RPT == 2 && TG::T0 == 1 && TG::D0 == 1 && TG::H2 % W == 0;
+#endif
+  // The residual code of the own quad hands subexpressions to the gather of the same step (a derivative at the site
+  // costs registers across one barrier instead of LDS reads and arithmetic twice).
+#ifdef PDE_AMD_NO_CARRY
+  constexpr bool CARRY = false;
+#else
+  constexpr bool CARRY = OWN && P::NCAR > 0;
+#endif
+  constexpr int HQ = TG::H2 / W;                          // rim quads at either end of a row
+  constexpr int NRIM = NRQ - NT;                          // with OWN: quads of the rim
   using ST = StagerQ<TF, P::PER0, P::PER1, P::PER2, NT, W>;
   static_assert(C::BWD_OK, "PDE not eligible for the quad marching adjoint");
 
@@ -518,7 +539,22 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int iraw = (ALT && j == RPT - 1 ? (int)threadIdx.x % (NT / 2) : (int)threadIdx.x) + j * NT;
-    const int i = iraw < NRQ ? iraw : 0;
+    int i = iraw < NRQ ? iraw : 0;
+    if (OWN) {      // region-linear index of the lane's own quad (round 0) or of rim quad number iraw - NT (round 1)
+      if (j == 0) {
+        i = ((int)threadIdx.x / QR + TG::H1) * GQR + HQ + owned_quad<QR, TG::S1, W>();
+      } else {
+        const int r = iraw < NRQ ? iraw - NT : 0;
+        constexpr int NROWS = 2 * TG::H1 * GQR;           // quads of the full rows above and below the tile
+        if (r < NROWS) {
+          const int rr = r / GQR;
+          i = (rr < TG::H1 ? rr : TG::T1 + rr) * GQR + r % GQR;
+        } else {
+          const int r2 = r - NROWS, c = HQ > 0 ? r2 % (2 * (HQ > 0 ? HQ : 1)) : 0, row = HQ > 0 ? r2 / (2 * (HQ > 0 ? HQ : 1)) : 0;
+          i = (TG::H1 + row) * GQR + (c < HQ ? c : QR + c);
+        }
+      }
+    }
     const int lq = i % GQR, rr = i / GQR;
     const int l2 = W * lq - TG::H2, l1 = rr % TG::D1 - TG::H1, l0 = rr / TG::D1 - TG::H0;
     bool ok = iraw < NRQ;
@@ -576,9 +612,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + min(max(n0 - 1, 0), g.TR - 1));
-  double lsum[P::NE];
+  // Loss sums of this lane: fp32 (non-negative terms, a few points per step over the frames of one chunk); the
+  // workgroup's and every later reduction are fp64.
+  float lsum[P::NE];
 #pragma unroll
-  for (int k = 0; k < P::NE; ++k) lsum[k] = 0.0;
+  for (int k = 0; k < P::NE; ++k) lsum[k] = 0.0f;
 
   // Frames are fetched two steps before the step that needs them in LDS: the loads of frame n+3 are issued
   // at the top of step n into one of two register sets and written to the ring at the end of step n+1, so a
@@ -622,8 +660,11 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
       cf[k] = to_vgpr(gvalid ? up[k] * wnext[k] : 0.0f);
       wnext[k] = ldc(a.wt, k * g.TR + min(max(n, 0), g.TR - 1));
     }
+    fv Gown[P::NE];      // OWN: the scaled residuals of the lane's own quad
+    float Cown[W][CARRY ? P::NCAR : 1];      // and the values its residual code hands to the same-frame adjoint
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
+    for (int jj = 0; jj < RPT; ++jj) {
+      const int j = OWN ? RPT - 1 - jj : jj;      // OWN: the rim first, so that the own quad's values are born last
       const bool mine = ALT ? ((int)threadIdx.x / (NT / 2) == half && (int)threadIdx.x % (NT / 2) + j * NT < NRQ)
                             : ((int)threadIdx.x + j * NT < NRQ);
       if (RPT * NT == NRQ || j < RPT - 1 || mine) {   // whole waves drop out of the last round
@@ -645,11 +686,12 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
           for (int px = 0; px < W; ++px) {
             racc.px = px; racc.i2 = r2[j] + px;
             float R[P::NE];
-            P::residual(racc, R);
+            if (CARRY && j == 0) P::residual_c(racc, R, Cown[px]);
+            else P::residual(racc, R);
 #pragma unroll
             for (int k = 0; k < P::NE; ++k) Gq[k][px] = WITH_LOSS ? R[k] : cf[k] * R[k];
           }
-          if (!rfull[j]) {      // off-lattice points carry no residual
+          if (!FULL && !rfull[j]) {      // off-lattice points carry no residual
 #pragma unroll
             for (int px = 0; px < W; ++px) {
               const int i2 = r2[j] + px;
@@ -659,7 +701,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
             }
           }
           if (WITH_LOSS) {      // Gq holds the residuals: their squares first, then the scaled residuals
-            if (rint[j]) {      // fp32 over the few points a lane sees in one step, fp64 across steps
+            if (OWN ? (j == 0 && rint[0]) : rint[j]) {      // fp32 over the few points a lane sees in one step, fp64 across steps
 #pragma unroll
               for (int k = 0; k < P::NE; ++k)
 #pragma unroll
@@ -671,11 +713,15 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
         }
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) *reinterpret_cast<fv*>(s_g + k * TG::SIZE + rG[j]) = Gq[k];
+        if (OWN && j == 0) {
+#pragma unroll
+          for (int k = 0; k < P::NE; ++k) Gown[k] = Gq[k];
+        }
       }
     }
     if (WITH_LOSS) {
 #pragma unroll
-      for (int k = 0; k < P::NE; ++k) lsum[k] += (double)lpart[k] * (double)wl[k];
+      for (int k = 0; k < P::NE; ++k) lsum[k] = fmaf(lpart[k], wl[k], lsum[k]);
     }
     PDE_AMD_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
@@ -693,7 +739,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
       aacc.ldsg = s_g + sG[q]; aacc.ldsx = s_x + sX[q];
       fv Gc[P::NE];
 #pragma unroll
-      for (int k = 0; k < P::NE; ++k) Gc[k] = *reinterpret_cast<const fv*>(s_g + k * TG::SIZE + sG[q]);
+      for (int k = 0; k < P::NE; ++k) Gc[k] = OWN ? Gown[k] : *reinterpret_cast<const fv*>(s_g + k * TG::SIZE + sG[q]);
       if (do_out) {
         aacc.ldsf = fprev + sF[q];
 #pragma unroll
@@ -726,7 +772,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
 #pragma unroll
         for (int px = 0; px < W; ++px) {
           aacc.px = px; aacc.i2 = pi2[q] + px;
-          P::adjoint_space(aacc, gs[px]);
+          if (CARRY) P::adjoint_space_c(aacc, Cown[px], gs[px]);
+          else P::adjoint_space(aacc, gs[px]);
         }
       }
 #pragma unroll
@@ -755,7 +802,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
     for (int f = 0; f < P::NF; ++f) st.touch(stage[f]);
     if (more) {
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + ((fnew % 3) * P::NF + f) * TF::SIZE);
+      for (int f = 0; f < P::NF; ++f) st.template store<FULL>(stage[f], s_f + ((fnew % 3) * P::NF + f) * TF::SIZE);
     }
     PDE_AMD_STAMP(6);
     // The gradient stores go out last: the wait for the prefetched frame above then covers loads only, and
@@ -763,7 +810,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
     if (do_out) {
 #pragma unroll
       for (int q = 0; q < QPT; ++q) {
-        if (inside[q]) {
+        if (FULL || inside[q]) {
 #pragma unroll
           for (int f = 0; f < P::NF; ++f)      // streamed: keeps the fields in cache
             BufIO<W>::store_nt(out[q][f], gbuf[f], goff[q], (unsigned)(n - 1) * frame_bytes);
@@ -787,7 +834,10 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   }
   if (WITH_LOSS) {
     __syncthreads();
-    block_sum_store<P::NE, NT>(lsum, s_red, a.partial + (long)w * P::NE);
+    double lsum64[P::NE];
+#pragma unroll
+    for (int k = 0; k < P::NE; ++k) lsum64[k] = (double)lsum[k];
+    block_sum_store<P::NE, NT>(lsum64, s_red, a.partial + (long)w * P::NE);
   }
 }
 

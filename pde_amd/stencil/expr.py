@@ -135,6 +135,17 @@ class Uni(E):
         return ("u", self.i)
 
 
+class Car(E):
+    """Value number i handed from the residual code to the adjoint code of the same site and frame (emission only)."""
+    __slots__ = ("i",)
+
+    def __init__(self, i: int):
+        self.i = i
+
+    def key(self):
+        return ("car", self.i)
+
+
 class Add(E):
     __slots__ = ("terms",)
 
@@ -318,7 +329,7 @@ def diff(e: E, r: Ref, memo=None) -> E:
         return memo[k]
     if isinstance(e, Ref):
         res = ONE if e == r else ZERO
-    elif isinstance(e, (Num, Par, Uni, Aux, GRef)):
+    elif isinstance(e, (Num, Par, Uni, Aux, GRef, Car)):
         res = ZERO
     elif isinstance(e, Add):
         res = add(*[diff(t, r, memo) for t in e.terms])
@@ -356,7 +367,7 @@ def shift(e: E, dt: int, do: O3, memo=None) -> E:
         res = Aux(e.a, addo(e.o, do))
     elif isinstance(e, GRef):
         res = GRef(e.k, e.ot + dt, addo(e.o, do))
-    elif isinstance(e, (Num, Par, Uni)):
+    elif isinstance(e, (Num, Par, Uni, Car)):
         res = e
     elif isinstance(e, Add):
         res = add(*[shift(t, dt, do, memo) for t in e.terms])
@@ -451,7 +462,7 @@ def hoist_uniforms(e: E, tab: UniformTable, memo=None) -> E:
     k = e.key()
     if k in memo:
         return memo[k]
-    if isinstance(e, (Num, Par, Uni, Ref, Aux, GRef)):
+    if isinstance(e, (Num, Par, Uni, Ref, Aux, GRef, Car)):
         res = e
     elif is_uniform(e):
         res = tab.ref(e)
@@ -477,6 +488,85 @@ def hoist_uniforms(e: E, tab: UniformTable, memo=None) -> E:
         res = psel(e.p, hoist_uniforms(e.a, tab, memo), hoist_uniforms(e.b, tab, memo))
     else:
         raise TypeError(type(e))
+    memo[k] = res
+    return res
+
+
+# ---------------------------------------------------------------------------
+# values shared by the residual and the adjoint of one site
+# ---------------------------------------------------------------------------
+# The recomputing adjoint evaluates the residuals and, one barrier later, the same-frame adjoint at the lane's own
+# points.  Subexpressions of field values that both contain (a derivative at the site, an upwind face value) can be
+# handed over in registers instead of being recomputed from LDS.
+
+def subtree_keys(exprs: Iterable[E]) -> set:
+    out: set = set()
+
+    def walk(e: E):
+        k = e.key()
+        if k in out:
+            return
+        out.add(k)
+        for ch in children(e):
+            walk(ch)
+
+    for e in exprs:
+        walk(e)
+    return out
+
+
+def op_count(e: E) -> int:
+    """Arithmetic operations of a tree (shared subtrees counted once per occurrence)."""
+    if isinstance(e, Add):
+        return len(e.terms) - 1 + sum(op_count(t) for t in e.terms)
+    if isinstance(e, Mul):
+        return len(e.factors) - 1 + sum(op_count(t) for t in e.factors)
+    if isinstance(e, Recip):
+        return 4 + op_count(e.e)
+    if isinstance(e, (Sel, PSel)):
+        return 1 + sum(op_count(c) for c in children(e))
+    return 0
+
+
+def find_carries(residuals: List[E], adjoint: List[E], min_ops: int = 2, limit: int = 8) -> List[E]:
+    """Maximal non-uniform subtrees of the adjoint expressions that also occur in the residuals, most expensive first."""
+    have = subtree_keys(residuals)
+    found: Dict[object, E] = {}
+
+    def walk(e: E):
+        if isinstance(e, (Num, Par, Uni, Ref, Aux, GRef, Car)) or is_uniform(e):
+            return
+        if e.key() in have and op_count(e) >= min_ops and not collect(e, GRef):
+            found.setdefault(e.key(), e)
+            return
+        for ch in children(e):
+            walk(ch)
+
+    for e in adjoint:
+        walk(e)
+    return sorted(found.values(), key=lambda x: -op_count(x))[:limit]
+
+
+def replace_subtrees(e: E, table: Dict[object, E], memo=None) -> E:
+    if memo is None:
+        memo = {}
+    k = e.key()
+    if k in memo:
+        return memo[k]
+    if k in table:
+        res = table[k]
+    elif isinstance(e, Add):
+        res = add(*[replace_subtrees(t, table, memo) for t in e.terms])
+    elif isinstance(e, Mul):
+        res = mul(*[replace_subtrees(t, table, memo) for t in e.factors])
+    elif isinstance(e, Recip):
+        res = recip(replace_subtrees(e.e, table, memo))
+    elif isinstance(e, Sel):
+        res = sel(replace_subtrees(e.c, table, memo), replace_subtrees(e.a, table, memo), replace_subtrees(e.b, table, memo))
+    elif isinstance(e, PSel):
+        res = psel(e.p, replace_subtrees(e.a, table, memo), replace_subtrees(e.b, table, memo))
+    else:
+        res = e
     memo[k] = res
     return res
 
@@ -530,13 +620,15 @@ class Emitter:
             return f"{a}.X({e.a},{e.o[0]},{e.o[1]},{e.o[2]})"
         if isinstance(e, GRef):
             return f"{a}.G({e.k},{e.ot},{e.o[0]},{e.o[1]},{e.o[2]})"
+        if isinstance(e, Car):
+            return f"C[{e.i}]"
         raise TypeError(type(e))
 
     def expr(self, e: E) -> str:
         k = e.key()
         if k in self.names:
             return self.names[k]
-        if isinstance(e, (Num, Par, Uni)):
+        if isinstance(e, (Num, Par, Uni, Car)):
             return self._atom(e)
         if isinstance(e, (Ref, Aux, GRef)):
             s = self._atom(e)
