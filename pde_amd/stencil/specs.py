@@ -58,7 +58,7 @@ class Spec:
     fused_slower: bool = False      # the one-pass step measured slower than forward + recomputing adjoint: 'fused' takes those
     hoist_uniforms: bool = True     # precompute products/sums of constants and per-sample parameters once per sample
     quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
-    carry_max: int = 0              # adjoint: at most this many values per point handed from the residual stage to the gather
+    carry_max: int = 6              # adjoint: at most this many values per point handed from the residual stage to the gather
 
     # derived
     def analyse(self):
@@ -202,7 +202,7 @@ def _tg2d():
     cont = dx(u) + dy(v)
     xm = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - nu * lap(u)
     ym = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - nu * lap(v)
-    return b.done([cont, xm, ym], threads_march=512, waves_per_simd=4, carry_max=4)
+    return b.done([cont, xm, ym], threads_march=512, waves_per_simd=4)
 
 
 def _advdiff2d():
