@@ -140,20 +140,25 @@ def upwind_flux_div(f: Q, u: Q, v: Q, ax_x: int, ax_y: int, inv_dx, inv_dy) -> Q
     East face of cell i carries velocity 0.5*(u[i] + u[i+1]) and the face value
     1.5 f[i] - 0.5 f[i-1] when that velocity is >= 0, else 1.5 f[i+1] - 0.5 f[i+2];
     the west face of cell i is the east face of cell i-1.
-    """
-    def face_flux(vel: Q, axis: int) -> Q:
-        vc = 0.5 * (vel + sh(vel, axis, 1))
-        pos = 1.5 * f - 0.5 * sh(f, axis, -1)
-        neg = 1.5 * sh(f, axis, 1) - 0.5 * sh(f, axis, 2)
-        return vc * qsel(vc, pos, neg)
 
-    fx = face_flux(u, ax_x)
-    fy = face_flux(v, ax_y)
-    return (fx - sh(fx, ax_x, -1)) * Q.lift(inv_dx) + (fy - sh(fy, ax_y, -1)) * Q.lift(inv_dy)
+    Evaluated with the halves pulled out: twice the face velocity (a plain sum, same sign) times twice the face value
+    (3 f[i] - f[i-1]), and one factor 0.25 on the grid constant.  Scaling by a power of two commutes with rounding, so
+    the values equal the textbook form's; the code is three multiplies per face and field shorter.
+    """
+    def face_flux4(vel: Q, axis: int) -> Q:
+        vs = vel + sh(vel, axis, 1)
+        pos = 3.0 * f - sh(f, axis, -1)
+        neg = 3.0 * sh(f, axis, 1) - sh(f, axis, 2)
+        return vs * qsel(vs, pos, neg)
+
+    fx = face_flux4(u, ax_x)
+    fy = face_flux4(v, ax_y)
+    return (fx - sh(fx, ax_x, -1)) * (0.25 * Q.lift(inv_dx)) + (fy - sh(fy, ax_y, -1)) * (0.25 * Q.lift(inv_dy))
 
 
 def face_div(u: Q, v: Q, ax_x: int, ax_y: int, inv_dx, inv_dy) -> Q:
-    """(uc_e - uc_w)/dx + (vc_n - vc_s)/dy with face velocities 0.5*(w[i] + w[i±1])."""
-    ue = 0.5 * (u + sh(u, ax_x, 1))
-    vn = 0.5 * (v + sh(v, ax_y, 1))
-    return (ue - sh(ue, ax_x, -1)) * Q.lift(inv_dx) + (vn - sh(vn, ax_y, -1)) * Q.lift(inv_dy)
+    """(uc_e - uc_w)/dx + (vc_n - vc_s)/dy with face velocities 0.5*(w[i] + w[i±1]); the halves are pulled out as in
+    upwind_flux_div, so that the face sums are shared with it."""
+    ue2 = u + sh(u, ax_x, 1)
+    vn2 = v + sh(v, ax_y, 1)
+    return (ue2 - sh(ue2, ax_x, -1)) * (0.5 * Q.lift(inv_dx)) + (vn2 - sh(vn2, ax_y, -1)) * (0.5 * Q.lift(inv_dy))
