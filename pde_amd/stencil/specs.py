@@ -202,7 +202,7 @@ def _tg2d():
     cont = dx(u) + dy(v)
     xm = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - nu * lap(u)
     ym = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - nu * lap(v)
-    return b.done([cont, xm, ym], threads_march=512, waves_per_simd=4)
+    return b.done([cont, xm, ym], threads_march=512, waves_per_simd=4, quad_prefetch=1)
 
 
 def _advdiff2d():
