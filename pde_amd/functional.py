@@ -284,17 +284,20 @@ def get_backend():
 def resolve_mode(mode: str, spec: str) -> str:
     """'auto' and 'fused' -> the kernels that run: 'recompute' (forward kernel, then an adjoint that re-evaluates the
     residuals), 'stored' (forward writes the residuals, the adjoint reads them) or 'fused' (one pass).  'auto' recomputes
-    where the PDE allows it, unless its spec says the stored kernels measured faster; 'fused' needs the recomputing adjoint
-    and yields to whichever of the other two the spec marks as faster for that PDE."""
+    where the PDE allows it, unless its spec says the stored kernels measured faster (`auto_stored`); 'fused' needs the
+    recomputing adjoint and yields to what 'auto' takes where the spec says the one-pass step measured slower
+    (`fused_slower`)."""
     if mode not in ("auto", "fused"):
         return mode
+    if mode == "fused" and os.environ.get("PDE_AMD_FORCE_FUSED") == "1" and _BACKEND.can_recompute(spec):
+        return "fused"      # diagnostic: measure the one-pass step where the spec prefers other kernels (tools/mode_sweep.sh)
     s = SPECS[spec]
     can = _BACKEND.can_recompute(spec)
-    if not can or s.auto_stored:
+    if not can:
         return "stored"
     if mode == "fused" and not s.fused_slower:
         return "fused"
-    return "recompute"
+    return "stored" if s.auto_stored else "recompute"
 
 
 class _ResidualLosses(torch.autograd.Function):

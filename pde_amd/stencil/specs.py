@@ -303,8 +303,8 @@ def _burgers2d_ch():
     rv = _ddt(b, v) + conv(v) - v * div - nu * lap(v)
     irr = _d1c4(b, v, 2, "dx") - _d1c4(b, u, 1, "dy")
     # adjoint: 171 VGPR at 2 points per lane; a 16 x 32 tile on 4 waves lets two workgroups share a CU (8 waves on 16 x 64 left room for one)
-    # [32, 9, 256, 256]: forward + recomputing adjoint 0.191 ms, the one-pass step 0.212 ms
-    return b.done([ru, rv, irr], quad_width_bwd=2, quad_prefetch=1, quad_bwd=(1, 16, 32), threads_quad_bwd=128, fused_slower=True)
+    # [32, 9, 256, 256]: forward + recomputing adjoint 0.205 ms, the one-pass step 0.185 ms
+    return b.done([ru, rv, irr], quad_width_bwd=2, quad_prefetch=1, quad_bwd=(1, 16, 32), threads_quad_bwd=128)
 
 
 def _active_matter():
@@ -315,7 +315,7 @@ def _active_matter():
     dT, dc = b.c("d_T", _k("d_T")), b.c("div_corr", _k("div_corr"))
     rc = _ddt(b, c) + conv(c) - dT * lap(c) - dc * c * div
     rd = _ddt(b, dxx) + conv(dxx) - dT * lap(dxx) - dc * dxx * div
-    # [16, 9, 256, 256]: stored residuals 0.129 ms, one-pass step 0.138 ms, forward + recomputing adjoint 0.151 ms
+    # [16, 9, 256, 256]: one-pass step 0.125 ms, stored residuals 0.127-0.134 ms, forward + recomputing adjoint 0.147 ms
     return b.done([div, rc, rd], **{**T2D_WIDE, "auto_stored": True})
 
 
@@ -504,7 +504,7 @@ def _heat3d():
     lap = _d2c2(b, u, 0, "dx") + _d2c2(b, u, 1, "dy") + _d2c2(b, u, 2, "dz")
     # forward and adjoint on the plane-marching kernels, residuals stored: step 0.125 ms on [2, 9, 128^3] against 0.171 ms
     # for the time-marching forward + recomputing adjoint and 0.149 ms for the fused step
-    return b.done([_ddt(b, u) - al * lap], **{**T3D, **Z3D, "z_first": True, "auto_stored": True})
+    return b.done([_ddt(b, u) - al * lap], **{**T3D, **Z3D, "z_first": True, "auto_stored": True, "fused_slower": True})      # [2, 9, 128^3]: stored 0.125 ms, one pass 0.139, recompute 0.166
 
 
 def _tg3d():

@@ -149,6 +149,30 @@ def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
         assert rel_l2(gr.cpu().numpy(), f.grad.numpy()) <= TOL
 
 
+def _whole_tile_variant(entry):
+    """Same case on a grid of whole tiles (1-D: 512 points; 2-D: 32 x 128): uncropped periodic classes then take the
+    adjoint instantiation that carries no lattice masks."""
+    cls, kw, shape, ps = entry
+    new = {1: (512,), 2: (32, 128)}[len(shape) - 2]
+    kw = dict(kw)
+    for old_n, new_n in zip(shape[2:], new):
+        for key in ("nx", "ny", "num_points"):
+            if kw.get(key) == old_n:
+                kw[key] = new_n
+    return (cls, kw, tuple(shape[:2]) + new, ps)
+
+
+WHOLE = [_whole_tile_variant(e) for e in SIZED[:len(SIZED) // 2] if len(e[2]) - 2 in (1, 2)]
+
+
+@pytest.mark.parametrize("mode", ["auto", "fused"])
+@pytest.mark.parametrize("cls,kw,shape,ps", WHOLE, ids=[s[0] for s in WHOLE])
+def test_whole_tile_grids_vs_oracle(cls, kw, shape, ps, mode):
+    """Grids that are a whole number of tiles along every axis: the periodic, uncropped classes run the mask-free
+    instantiation of the marching adjoint, which no ragged case reaches."""
+    test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode)
+
+
 @pytest.mark.parametrize("mode", ["auto", "stored", "fused"])
 @pytest.mark.parametrize("width", [70, 72])
 def test_per_t_scales_offsets_and_guards_at_tile_sizes(width, mode):
