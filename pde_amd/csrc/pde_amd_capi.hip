@@ -160,6 +160,15 @@ struct Ops {
     return (P::PER0 || C::HB0 == 0) && (P::PER1 || C::HB1 == 0) && (P::PER2 || C::HB2 == 0) && P::NA == 0;
   }
 
+  // the same for the marching forward kernel (its tiles and halos)
+  static bool full_grid_fwd(const pde_amd_problem* p) {
+    using TL = typename QuadCfg<P, P::QWF>::TL;
+    for (int a = 0; a < 3; ++a)
+      if (p->lo[a] != 0 || p->hi[a] != 0) return false;
+    if (p->n[0] % P::QF0 != 0 || p->n[1] % P::QF1 != 0 || p->n[2] % P::QF2 != 0) return false;
+    return (P::PER0 || TL::H0 == 0) && (P::PER1 || TL::H1 == 0) && (P::PER2 || TL::H2 == 0) && P::NA == 0;
+  }
+
   static long fwd_tiles(const pde_amd_problem* p) {
     return (long)cdiv(p->n[0], P::FT0) * cdiv(p->n[1], P::FT1) * cdiv(p->n[2], P::FT2);
   }
@@ -259,7 +268,10 @@ struct Ops {
         a.chunk = pick_chunk(p->batch * qtiles, (int)tr);
         items = cdiv((int)tr, a.chunk) * qtiles;
         if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
-        hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF, false>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
+        if (full_grid_fwd(p))
+          hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF, false, true>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
+        else
+          hipLaunchKernelGGL((fwd_march_q_kernel<P, P::QWF, false>), dim3((unsigned)(p->batch * items)), dim3(QuadCfg<P, P::QWF>::NT), 0, stream, a);
       }
     } else if (!QuadCfg<P, P::QWF>::FWD_OK && FrameCfg<P, P::QWF>::OK && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
                (!P::NA || aligned_vec<P::NA, P::QWF>(aux))) {

@@ -222,7 +222,8 @@ struct QuadCfg {
 // ------------------------------------------------------------------------------------------------
 // forward, marching, quads: workgroup = (sample, chunk of residual frames, tile)
 // ------------------------------------------------------------------------------------------------
-template <class P, int W, bool WRITE_R>
+// FULL: as in the adjoint below, the host has checked that no quad of any lane can leave the lattice.
+template <class P, int W, bool WRITE_R, bool FULL = false>
 __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kernel(const Args a) {
   using C = QuadCfg<P, W>;
   using fv = typename VecOf<W>::type;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
         acc.px = px; acc.i2 = pi2[q] + px;
         P::residual(acc, Rq[px]);
       }
-      if (!wfull[q]) {      // off-lattice points contribute nothing
+      if (!FULL && !wfull[q]) {      // off-lattice points contribute nothing
 #pragma unroll
         for (int px = 0; px < W; ++px) {
           const int i2 = pi2[q] + px;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
       for (int px = 0; px < W; ++px)
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) part[k] += Rq[px][k] * Rq[px][k];
-      if (WRITE_R && pi0[q] < g.N0 && pi1[q] < g.N1 && pi2[q] < g.N2) {      // stored mode: residuals on the full grid, zeros off the lattice
+      if (WRITE_R && (FULL || (pi0[q] < g.N0 && pi1[q] < g.N1 && pi2[q] < g.N2))) {      // stored mode: residuals on the full grid, zeros off the lattice
         const long ro = ((long)b * g.TR + (tau - P::TLO)) * g.S + ((long)pi0[q] * g.N1 + pi1[q]) * g.N2 + pi2[q];
 #pragma unroll
         for (int k = 0; k < P::NE; ++k) {
@@ -373,7 +374,7 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NT), P::WPSF) void fwd_march_q_kern
     if (more) {
       __syncthreads();
 #pragma unroll
-      for (int f = 0; f < P::NF; ++f) st.store(stage[f], s_f + RL::tile(f, fnew % NS) * TL::SIZE);
+      for (int f = 0; f < P::NF; ++f) st.template store<FULL>(stage[f], s_f + RL::tile(f, fnew % NS) * TL::SIZE);
       __syncthreads();
     }
   }
