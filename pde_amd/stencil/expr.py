@@ -547,6 +547,75 @@ def find_carries(residuals: List[E], adjoint: List[E], min_ops: int = 2, limit: 
     return sorted(found.values(), key=lambda x: -op_count(x))[:limit]
 
 
+def share_products(exprs: List[E]) -> List[E]:
+    """Products that contain another product of the same expressions as a sub-product are regrouped around it
+    (u * c * d  with  c * d  elsewhere  ->  u * (c * d)), so that the emitter's temporaries share the multiplication."""
+    muls: Dict[object, Mul] = {}
+
+    def walk(e: E, seen: set):
+        k = e.key()
+        if k in seen:
+            return
+        seen.add(k)
+        if isinstance(e, Mul):
+            muls[k] = e
+        for ch in children(e):
+            walk(ch, seen)
+
+    seen: set = set()
+    for e in exprs:
+        walk(e, seen)
+    small = sorted((m for m in muls.values() if len(m.factors) >= 2), key=lambda m: -len(m.factors))
+
+    def regroup(e: E, memo: Dict[object, E]) -> E:
+        k = e.key()
+        if k in memo:
+            return memo[k]
+        if isinstance(e, Add):
+            res = Add([regroup(t, memo) for t in e.terms])
+        elif isinstance(e, Mul):
+            facs = list(e.factors)
+            keys = [f.key() for f in facs]
+            inner = None
+            if len(facs) >= 3:
+                for m in small:
+                    if len(m.factors) >= len(facs) or m.key() == k:
+                        continue
+                    left = list(keys)
+                    ok = True
+                    for f in m.factors:
+                        if f.key() in left:
+                            left.remove(f.key())
+                        else:
+                            ok = False
+                            break
+                    if ok:
+                        inner = m
+                        rest = []
+                        need = [f.key() for f in m.factors]
+                        for f in facs:
+                            if f.key() in need:
+                                need.remove(f.key())
+                            else:
+                                rest.append(f)
+                        facs = rest + [m]
+                        break
+            res = Mul([f if f is inner else regroup(f, memo) for f in facs])
+        elif isinstance(e, Recip):
+            res = Recip(regroup(e.e, memo))
+        elif isinstance(e, Sel):
+            res = Sel(regroup(e.c, memo), regroup(e.a, memo), regroup(e.b, memo))
+        elif isinstance(e, PSel):
+            res = PSel(e.p, regroup(e.a, memo), regroup(e.b, memo))
+        else:
+            res = e
+        memo[k] = res
+        return res
+
+    memo: Dict[object, E] = {}
+    return [regroup(e, memo) for e in exprs]
+
+
 def replace_subtrees(e: E, table: Dict[object, E], memo=None) -> E:
     if memo is None:
         memo = {}

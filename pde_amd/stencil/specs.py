@@ -123,6 +123,17 @@ def _d1c2(b, q, axis, h): return stencil(q, axis, C2_D1, b.c("inv2" + h, _inv2(h
 def _ddt(b, q): return dt_central(q, b.c("inv2dt", _inv2dt))
 
 
+def _lap_c4_grouped(b, q, coef, ax_x, hx, ax_y, hy):
+    """coef * (d2c4_x + d2c4_y)(q) with the taps of equal weight added before they are scaled: four additions and five
+    multiply-adds with per-sample coefficients instead of two five-tap sums, two scalings and the product with coef (the
+    values differ from that form only in the order of rounding)."""
+    cx, cy = b.c("inv12" + hx + "2", _inv12sq(hx)), b.c("inv12" + hy + "2", _inv12sq(hy))
+    s1x, s2x = sh(q, ax_x, 1) + sh(q, ax_x, -1), sh(q, ax_x, 2) + sh(q, ax_x, -2)
+    s1y, s2y = sh(q, ax_y, 1) + sh(q, ax_y, -1), sh(q, ax_y, 2) + sh(q, ax_y, -2)
+    return ((16.0 * coef * cx) * s1x - (coef * cx) * s2x + (16.0 * coef * cy) * s1y - (coef * cy) * s2y
+            - (30.0 * coef * (cx + cy)) * q)
+
+
 SPECS: Dict[str, Spec] = {}
 
 
@@ -198,10 +209,10 @@ def _tg2d():
     nu = b.s("nu")
     dx = lambda q: _d1c4(b, q, 2, "dx")
     dy = lambda q: _d1c4(b, q, 1, "dy")
-    lap = lambda q: _d2c4(b, q, 2, "dx") + _d2c4(b, q, 1, "dy")
+    visc = lambda q: _lap_c4_grouped(b, q, nu, 2, "dx", 1, "dy")
     cont = dx(u) + dy(v)
-    xm = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - nu * lap(u)
-    ym = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - nu * lap(v)
+    xm = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - visc(u)
+    ym = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - visc(v)
     return b.done([cont, xm, ym], threads_march=512, waves_per_simd=4, quad_prefetch=1)
 
 

@@ -111,3 +111,18 @@ def test_taylor_green_carries_its_four_derivatives():
     from pde_amd.stencil.codegen import emit_spec
     txt = emit_spec(SPECS["tg2d"])
     assert "static constexpr int NCAR = 4;" in txt and "residual_c" in txt and "adjoint_space_c" in txt
+
+
+@pytest.mark.parametrize("name", sorted(SPECS))
+def test_shared_products_keep_their_value(name):
+    """Regrouping products around sub-products that occur elsewhere (expr.share_products) changes no value."""
+    s = SPECS[name]
+    random.seed(hash(name) & 0xff)
+    tab = X.UniformTable()
+    res = [X.hoist_uniforms(e, tab) for e in s.residuals]
+    shared = X.share_products(res)
+    for trial in range(3):
+        env = {}
+        for e, h in zip(res, shared):
+            a, b = _value(e, env, tab), _value(h, env, tab)
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (name, a, b)
