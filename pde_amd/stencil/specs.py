@@ -283,11 +283,20 @@ def _kp2d():
 
 
 # ---- 2-D n-PINN upwind family ------------------------------------------------------------------
+def _lap_c2_grouped(b, q, coef, ax_x, hx, ax_y, hy):
+    """coef * (d2c2_x + d2c2_y)(q) with each pair of neighbours added before it is scaled and one centre term: two
+    additions and three multiply-adds with the coefficient folded into the grid constants, instead of two three-tap sums,
+    their scalings and the product with coef."""
+    cx, cy = b.c("inv_" + hx + "2", _inv(hx, 2)), b.c("inv_" + hy + "2", _inv(hy, 2))
+    return ((coef * cx) * (sh(q, ax_x, 1) + sh(q, ax_x, -1)) + (coef * cy) * (sh(q, ax_y, 1) + sh(q, ax_y, -1))
+            - (2.0 * coef * (cx + cy)) * q)
+
+
 def _npinn_parts(b, u, v, ax_x, ax_y):
     idx, idy = b.c("inv_dx", _inv("dx")), b.c("inv_dy", _inv("dy"))
     div = face_div(u, v, ax_x, ax_y, idx, idy)
     conv = lambda f: upwind_flux_div(f, u, v, ax_x, ax_y, idx, idy)
-    lap = lambda f: _d2c2(b, f, ax_x, "dx") + _d2c2(b, f, ax_y, "dy")
+    lap = lambda f, coef: _lap_c2_grouped(b, f, coef, ax_x, "dx", ax_y, "dy")      # coef * laplacian(f)
     return div, conv, lap
 
 
@@ -297,9 +306,9 @@ def _shear_flow():
     u, v, p, s = b.F()
     div, conv, lap = _npinn_parts(b, u, v, 1, 2)
     nu, D, dc = b.c("nu", _k("nu")), b.c("D", _k("D")), b.c("div_corr", _k("div_corr"))
-    ru = _ddt(b, u) + conv(u) + _d1c2(b, p, 1, "dx") - nu * lap(u) - dc * u * div
-    rv = _ddt(b, v) + conv(v) + _d1c2(b, p, 2, "dy") - nu * lap(v) - dc * v * div
-    rs = _ddt(b, s) + conv(s) - D * lap(s) - dc * s * div
+    ru = _ddt(b, u) + conv(u) + _d1c2(b, p, 1, "dx") - lap(u, nu) - dc * u * div
+    rv = _ddt(b, v) + conv(v) + _d1c2(b, p, 2, "dy") - lap(v, nu) - dc * v * div
+    rs = _ddt(b, s) + conv(s) - lap(s, D) - dc * s * div
     # adjoint tile 16 x 32: its residual region (tile + 2 each way) is 1.41x the tile instead of 1.59x for 8 x 64
     return b.done([div, ru, rv, rs], **{**T2D_WIDE, 'quad_bwd': (1, 16, 32)})
 
@@ -310,8 +319,8 @@ def _burgers2d_ch():
     u, v = b.F()
     nu = b.s("nu")
     div, conv, lap = _npinn_parts(b, u, v, 2, 1)
-    ru = _ddt(b, u) + conv(u) - u * div - nu * lap(u)
-    rv = _ddt(b, v) + conv(v) - v * div - nu * lap(v)
+    ru = _ddt(b, u) + conv(u) - u * div - lap(u, nu)
+    rv = _ddt(b, v) + conv(v) - v * div - lap(v, nu)
     irr = _d1c4(b, v, 2, "dx") - _d1c4(b, u, 1, "dy")
     # adjoint: 171 VGPR at 2 points per lane; a 16 x 32 tile on 4 waves lets two workgroups share a CU (8 waves on 16 x 64 left room for one)
     # [32, 9, 256, 256]: forward + recomputing adjoint 0.205 ms, the one-pass step 0.185 ms
@@ -324,8 +333,8 @@ def _active_matter():
     u, v, c, dxx = b.F()
     div, conv, lap = _npinn_parts(b, u, v, 2, 1)
     dT, dc = b.c("d_T", _k("d_T")), b.c("div_corr", _k("div_corr"))
-    rc = _ddt(b, c) + conv(c) - dT * lap(c) - dc * c * div
-    rd = _ddt(b, dxx) + conv(dxx) - dT * lap(dxx) - dc * dxx * div
+    rc = _ddt(b, c) + conv(c) - lap(c, dT) - dc * c * div
+    rd = _ddt(b, dxx) + conv(dxx) - lap(dxx, dT) - dc * dxx * div
     # [16, 9, 256, 256]: one-pass step 0.125 ms, stored residuals 0.127-0.134 ms, forward + recomputing adjoint 0.147 ms
     return b.done([div, rc, rd], **{**T2D_WIDE, "auto_stored": True})
 
@@ -553,8 +562,8 @@ def _ns_incom():
     nu, dc = b.c("nu", _k("nu")), b.c("div_corr", _k("div_corr"))
     px = (0.5 * (p + sh(p, 1, 1)) - 0.5 * (sh(p, 1, -1) + p)) * idx
     py = (0.5 * (p + sh(p, 2, 1)) - 0.5 * (sh(p, 2, -1) + p)) * idy
-    ru = _ddt(b, u) + conv(u) + px - nu * lap(u) - d * fx - dc * u * div
-    rv = _ddt(b, v) + conv(v) + py - nu * lap(v) - d * fy - dc * v * div
+    ru = _ddt(b, u) + conv(u) + px - lap(u, nu) - d * fx - dc * u * div
+    rv = _ddt(b, v) + conv(v) + py - lap(v, nu) - d * fy - dc * v * div
     rd = _ddt(b, d) + conv(d) - dc * d * div
     return b.done([div, ru, rv, rd], **{**T2D_WIDE, 'quad_bwd': (1, 16, 32)})
 
