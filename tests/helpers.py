@@ -57,3 +57,19 @@ def rel_l2(a, b):
     d = np.linalg.norm((a - b).ravel())
     n = np.linalg.norm(b.ravel())
     return d / n if n > 0 else d
+
+
+class RolloutStubModel:
+    """A deterministic stand-in for the trained model of tools/eval_rollout.py (called as model(x, return_normalized=True),
+    returns the normalised output with its per-channel mean and std): its output depends on its input, so a rollout that
+    feeds predictions back differs from the one-step evaluation.  Used to produce the rollout fixture and to replay it."""
+
+    def eval(self):
+        return self
+
+    def __call__(self, x, return_normalized=True):
+        C = x.shape[-1]
+        ramp = torch.linspace(0.0, 1.0, C, dtype=x.dtype, device=x.device).view(1, 1, 1, 1, C)
+        mean, std = 0.4 * ramp - 0.2, 0.8 + 0.4 * ramp
+        out = 0.55 * torch.roll(x, shifts=1, dims=2) + 0.35 * torch.tanh(x) + 0.1 * torch.roll(x, shifts=-1, dims=3)
+        return (out - mean) / std, mean, std

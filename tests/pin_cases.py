@@ -196,5 +196,17 @@ def check_boundary_6d(dev):
         assert np.array_equal(p.grad.cpu().numpy() != 0, Z[f"bc6d_w{w}_grad"] != 0)
 
 
+def check_rollout_loop(dev):
+    """evaluate_rollout against the result of the reference's own loop (tools/eval_rollout.py:94-146) on the same stub model"""
+    import json
+    from pde_amd import rollout as PR
+    from tests.helpers import RolloutStubModel
+    chans = [tuple(c) for c in json.loads(bytes(Z["rollout_channels"]).decode())]
+    data = _f32("rollout_data", dev)
+    one, roll = PR.evaluate_rollout(PR.denormalised(RolloutStubModel()), data, int(Z["rollout_t_input"]), chans, device=dev)
+    assert np.allclose([one[n] for _, n in chans], Z["rollout_one_step"], rtol=TOL, atol=0)
+    assert np.allclose([roll[n] for _, n in chans], Z["rollout_rollout"], rtol=10 * TOL, atol=0)      # fp32 predictions fed back
+
+
 CHECKS = {f.__name__[6:]: f for f in (check_gray_scott_fd, check_heat3d, check_tg3d, check_ns_incom, check_taylor_green_2d_alias,
-                                      check_periodic_bc, check_eval_nrmse, check_boundary_6d)}
+                                      check_periodic_bc, check_eval_nrmse, check_boundary_6d, check_rollout_loop)}

@@ -110,3 +110,17 @@ def test_boundary_loss_on_6d_tensor():
         val.backward()
         assert abs(float(val) - float(Z[f"bc6d_w{w}"])) <= 1e-13 * float(val)
         assert rel_l2(q.grad.numpy(), Z[f"bc6d_w{w}_grad"]) <= 1e-13
+
+
+def test_rollout_loop():
+    """tools/eval_rollout.py:94-146 (`evaluate`, extracted from the script and run around tests/helpers.py's stub model)"""
+    from tests.helpers import RolloutStubModel
+    model = RolloutStubModel()
+
+    def predict(x):
+        out, mean, std = model(x)
+        return out * std + mean
+    chans = [tuple(c) for c in J("rollout_channels")]
+    one, roll = GO.rollout_evaluate(predict, T("rollout_data"), int(Z["rollout_t_input"]), chans)
+    assert np.allclose([one[n] for _, n in chans], Z["rollout_one_step"], rtol=1e-12, atol=0)
+    assert np.allclose([roll[n] for _, n in chans], Z["rollout_rollout"], rtol=1e-12, atol=0)

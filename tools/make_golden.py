@@ -349,8 +349,8 @@ def load_class(path, name, extra_globals=None):
 def run_pins():
     """Fixtures from the reference's own verification code for what has no class in the reference tree (or lives inside
     a driver loop): the FD-c4 Gray-Scott residuals, the 3-D heat and 3-D Taylor-Green verifiers, the n-PINN residuals of
-    the inhomogeneous incompressible NS test, the periodic-BC loss, the eval_nrmse loop, and the boundary loss that the
-    3-D Burgers trainer applies to a 6-D tensor."""
+    the inhomogeneous incompressible NS test, the periodic-BC loss, the eval_nrmse loop, the boundary loss that the
+    3-D Burgers trainer applies to a 6-D tensor, and the one-step / rollout evaluation loop."""
     out = {}
     g = torch.Generator().manual_seed(2024)
     rnd = lambda *shape: torch.randn(*shape, generator=g, dtype=torch.float64)
@@ -488,6 +488,26 @@ def run_pins():
         val = f(q, t6, m6, w)
         val.backward()
         out[f"bc6d_w{w}"], out[f"bc6d_w{w}_grad"] = val.detach().numpy(), q.grad.numpy()
+
+    # -- one-step and rollout evaluation loop: tools/eval_rollout.py:94-146 around a stub model whose output depends on
+    #    its input (the script's own imports, h5py among them, are not needed by the function)
+    import importlib.util      # by path: the reference tree on sys.path has a `tests` package of its own
+    hspec = importlib.util.spec_from_file_location("pde_amd_test_helpers", os.path.join(os.path.dirname(OUT), "helpers.py"))
+    helpers = importlib.util.module_from_spec(hspec)
+    hspec.loader.exec_module(helpers)
+    RolloutStubModel = helpers.RolloutStubModel
+    nps = load_function("tools/eval_rollout.py", "nrmse_per_sample")
+    npc = load_function("tools/eval_rollout.py", "nrmse_per_channel", dict(nrmse_per_sample=nps))
+    ev = load_function("tools/eval_rollout.py", "evaluate", dict(nrmse_per_channel=npc))
+    g2 = torch.Generator().manual_seed(515)
+    data = torch.randn(3, 7, 6, 5, 18, generator=g2, dtype=torch.float64)
+    chans = [(0, "vx"), (4, "c4"), (15, "p")]
+    one, roll = ev(RolloutStubModel(), data, 3, chans, torch.device("cpu"))
+    out["rollout_data"] = data.numpy()
+    out["rollout_t_input"] = np.asarray(3)
+    out["rollout_channels"] = np.frombuffer(json.dumps(chans).encode(), dtype=np.uint8)
+    out["rollout_one_step"] = np.asarray([one[n] for _, n in chans])
+    out["rollout_rollout"] = np.asarray([roll[n] for _, n in chans])
     return out
 
 
