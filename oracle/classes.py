@@ -153,6 +153,18 @@ _mk("ShearFlowPDELossNPINN", ("continuity", "x_momentum", "y_momentum", "tracer"
     guarded=("x_momentum", "y_momentum", "tracer"), per_t="helper")
 
 
+def _shear_central(s, u, v, p, sc, reduction="mean", t_offset=None):
+    k = s.kw
+    return s.finish(O.residuals_shear_flow_central(u, v, p, sc, dx=k["Lx"] / k["nx"], dy=k["Ly"] / k["ny"], dt=k["dt"], nu=k["nu"],
+                                                   D=k["D"]), t_offset)
+
+
+# parity unpinned: see residuals_shear_flow_central
+_mk("ShearFlowPDELoss", ("continuity", "u_momentum", "v_momentum", "tracer"),
+    dict(nx=256, ny=512, Lx=1.0, Ly=2.0, dt=0.1, nu=1e-4, D=1e-3), _shear_central,
+    guarded=("u_momentum", "v_momentum", "tracer"), per_t="helper", total_key=True)
+
+
 class _B2CH(_Cls):
     def fixed_scale(self, eq):
         s = float(self.scales[eq])

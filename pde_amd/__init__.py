@@ -6,7 +6,7 @@ arithmetic runs in hand-written HIP kernels behind a C ABI (include/pde_amd.h).
 from .losses import (  # noqa: F401
     StencilPDELoss, Burgers1DPDELoss, Advection1DPDELoss, Heat1DPDELoss, APEBenchBurgers1DPDELoss, KS1DPDELoss,
     KdV1DPDELoss, TaylorGreen2DPDELoss, AdvDiff2DPDELoss, AnisoDiff2DPDELoss, Wave2DPDELoss,
-    APEBenchBurgers2DPDELoss, NSPwCPDELoss, KP2DPDELoss, ShearFlowPDELossNPINN, Burgers2DCHPDELoss,
+    APEBenchBurgers2DPDELoss, NSPwCPDELoss, KP2DPDELoss, ShearFlowPDELossNPINN, ShearFlowPDELoss, Burgers2DCHPDELoss,
     ActiveMatterNPINNPDELoss, RayleighBenardFullPDELoss, TurbulentRadiativePDELoss, WaveGaussPDELoss,
     GrayScottPDELoss, Advection3DPDELoss, APEBenchBurgers3DPDELoss, SwiftHohenberg3DPDELoss, Heat3DPDELoss,
     TaylorGreenPDELoss, TaylorGreen3DPDELoss, NSIncomPDELoss, ActiveMatterPDELoss, ViscoelasticContinuityLoss,

@@ -590,6 +590,36 @@ class ShearFlowPDELossNPINN(StencilPDELoss):
         return self._evaluate([u, v, p, s], t_offset=t_offset)
 
 
+class ShearFlowPDELoss(StencilPDELoss):
+    """Central-difference residuals of the periodic shear-flow system (continuity, u_momentum, v_momentum, tracer).
+
+    The reference's tools import this class from finetune/pde_loss_verified.py and construct it as
+    ShearFlowPDELoss(nx, ny, Lx, Ly, dt, nu, D) (tools/test_gt_npinn_vs_central.py:82-85, tools/test_gt_fp32_pde_bc.py:52-55,
+    tools/test_gt_pde_all_samples.py:193), call it as pde_fn(u, v, p, s, reduction='mean' | 'none') and read the four keys
+    above (test_gt_fp32_pde_bc.py:117-121, test_gt_pde_all_samples.py:104-123), but the snapshot holds neither its
+    definition nor a verification of its arithmetic.  Constructor, call and keys follow those call sites; the arithmetic is
+    the advective form with the file's 4th-order periodic central stencils (x along dim -2, y along dim -1, like the n-PINN
+    class of the same system).  Parity with the original class is therefore unpinned; the kernels are checked against the
+    CPU restatement of this same arithmetic."""
+    SPEC, EQS = "shear_flow_central", ("continuity", "u_momentum", "v_momentum", "tracer")
+    GUARDED, PER_T, PER_T_FLAG = ("u_momentum", "v_momentum", "tracer"), "helper", "has_per_t_scales"
+    TOTAL_KEY = True      # tools/test_gt_pde_all_samples.py:104 reads losses['total'] beside the four equations
+    DEFAULT_EQ_SCALES = {"continuity": 1.0, "u_momentum": 1.0, "v_momentum": 1.0, "tracer": 1.0}
+
+    def __init__(self, nx: int = 256, ny: int = 512, Lx: float = 1.0, Ly: float = 2.0, dt: float = 0.1,
+                 nu: float = 1e-4, D: float = 1e-3, eq_scales=None, eq_weights=None, eq_scales_per_t=None):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.dx, self.dy, self.dt, self.nu, self.D = Lx / nx, Ly / ny, dt, nu, D
+        self._init_common(self.DEFAULT_EQ_SCALES, eq_scales, eq_weights, eq_scales_per_t)
+
+    def _params(self):
+        return dict(dx=self.dx, dy=self.dy, dt=self.dt, nu=self.nu, D=self.D)
+
+    def forward(self, u: Tensor, v: Tensor, p: Tensor, s: Tensor, reduction: str = "mean", t_offset: Optional[Tensor] = None):
+        return self._evaluate([u, v, p, s], t_offset=t_offset, reduction=reduction)
+
+
 class Burgers2DCHPDELoss(StencilPDELoss):
     """finetune/pde_loss_verified.py:2079-2362"""
     SPEC, EQS = "burgers2d_ch", ("u_momentum", "v_momentum", "irrotational")

@@ -568,11 +568,30 @@ def _ns_incom():
     return b.done([div, ru, rv, rd], **{**T2D_WIDE, 'quad_bwd': (1, 16, 32)})
 
 
+def _shear_flow_central():
+    # ShearFlowPDELoss: the central-difference class the reference's tools construct (tools/test_gt_npinn_vs_central.py:82-85,
+    # tools/test_gt_fp32_pde_bc.py:52-55, called as pde_fn(u, v, p, s, reduction=...) with the keys continuity, u_momentum,
+    # v_momentum, tracer) but whose definition the snapshot does not hold.  Arithmetic chosen here: the advective form with the
+    # 4th-order periodic central stencils of the file's other periodic classes (:1769-1790); x dim -2 (dx), y dim -1 (dy)
+    # as in the n-PINN class of the same system.
+    b = _B("shear_flow_central", 2, ["u", "v", "p", "s"], ["continuity", "u_momentum", "v_momentum", "tracer"])
+    u, v, p, s = b.F()
+    nu, D = b.c("nu", _k("nu")), b.c("D", _k("D"))
+    dx = lambda q: _d1c4(b, q, 1, "dx")
+    dy = lambda q: _d1c4(b, q, 2, "dy")
+    visc = lambda q, c: _lap_c4_grouped(b, q, c, 1, "dx", 2, "dy")
+    cont = dx(u) + dy(v)
+    ru = _ddt(b, u) + u * dx(u) + v * dy(u) + dx(p) - visc(u, nu)
+    rv = _ddt(b, v) + u * dx(v) + v * dy(v) + dy(p) - visc(v, nu)
+    rs = _ddt(b, s) + u * dx(s) + v * dy(s) - visc(s, D)
+    return b.done([cont, ru, rv, rs], **{**T2D_WIDE, 'quad_bwd': (1, 16, 32)})
+
+
 for _f in (_burgers1d, _advection1d, _heat1d, _ape_burgers1d, _ks1d, _kdv1d, _tg2d, _advdiff2d, _anisodiff2d,
            _wave2d, _ape_burgers2d, _nspwc, _kp2d, _shear_flow, _burgers2d_ch, _active_matter,
            _rayleigh_benard, _turbulent_radiative, _wave_gauss, _burgers2d_ghost, _gray_scott_fd,
            _gray_scott_pw, _advection3d, _ape_burgers3d, _swift_hohenberg3d, _heat3d, _tg3d, _ns_incom,
-           _active_matter_fft, _viscoelastic_cont, _flow_mixing_v2):      # new PDEs go last: ids are part of the C ABI
+           _active_matter_fft, _viscoelastic_cont, _flow_mixing_v2, _shear_flow_central):      # new PDEs go last: ids are part of the C ABI
     _reg(_f())
 
 PDE_IDS = {name: i for i, name in enumerate(SPECS)}

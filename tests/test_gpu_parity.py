@@ -68,6 +68,7 @@ SIZED = [
     ("Burgers1DPDELoss", dict(dx=0.02, dt=0.01), (3, 7, 300), dict(nu=(0.005, 0.1))),
     ("TaylorGreen2DPDELoss", dict(nx=72, ny=50, Lx=6.28, Ly=6.28, dt=0.01), (3, 6, 50, 72), dict(nu=(0.01, 0.1))),
     ("ShearFlowPDELossNPINN", dict(nx=40, ny=70, Lx=1.0, Ly=2.0, dt=0.1), (2, 5, 40, 70), {}),
+    ("ShearFlowPDELoss", dict(nx=40, ny=70, Lx=1.0, Ly=2.0, dt=0.1, nu=0.01, D=0.02), (2, 5, 40, 70), {}),
     ("RayleighBenardFullPDELoss", dict(nx=48, ny=40, Lx=4.0, Ly=1.0, dt=0.25, skip_bl=3), (2, 5, 48, 40), dict(kappa=(1e-3, 1e-2))),
     ("Burgers2DCHPDELoss", dict(nx=66, ny=20, dt=0.01), (2, 4, 20, 66), dict(nu=(0.01, 0.1))),
     ("KP2DPDELoss", dict(dx=0.1, dy=0.1, dt=0.01, skip_boundary=5), (2, 5, 30, 70), {}),
