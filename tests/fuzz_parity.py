@@ -37,7 +37,9 @@ def reach(spec):
     return r
 
 
-def one_case(name, rng, dev, hip, interp, quad):
+def one_case(name, rng, dev, hip, interp, quad, whole=False):
+    """quad: the fastest extent is a multiple of four (register-blocked kernels).  whole: extents that are whole numbers of
+    the kernels' tiles and no crop on periodic axes, which selects the mask-free instantiations where the PDE has them."""
     s = SPECS[name]
     nd = s.ndim
     B = int(rng.integers(1, 4))
@@ -50,11 +52,15 @@ def one_case(name, rng, dev, hip, interp, quad):
         sp = [int(rng.integers(5, 30)), int(rng.integers(5, 22)), int(rng.integers(8, 50))]      # the interpreter keeps every node's array
     if quad:
         sp[-1] = (sp[-1] + 3) // 4 * 4
+    if whole:
+        lcm = lambda a, b: a * b // np.gcd(a, b)
+        unit = [int(lcm(s.quad_bwd[a], s.quad_fwd[a])) for a in range(3 - nd, 3)]
+        sp = [u * max(int(rng.integers(1, 3 if u >= 32 else 4)), -(-8 // u)) for u in unit]      # at least 8 points: periodic halos
     full = [1] * (3 - nd) + sp
     rc = reach(s)
     lo, hi = [0, 0, 0], [0, 0, 0]
     for a in range(3 - nd, 3):
-        extra_lo, extra_hi = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        extra_lo, extra_hi = (0, 0) if whole else (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
         base = 0 if s.periodic[a] else rc[a]      # wall axes: keep the stencil inside the grid (zeros beyond it feed divisions)
         lo[a], hi[a] = base + extra_lo, base + extra_hi
         if lo[a] + hi[a] >= full[a]:
@@ -110,7 +116,7 @@ def main():
         if args.only and name not in args.only:
             continue
         for c in range(args.cases):
-            desc, bad = one_case(name, rng, dev, hip, interp, quad=(c % 2 == 1))
+            desc, bad = one_case(name, rng, dev, hip, interp, quad=(c % 2 == 1), whole=(c % 3 == 2))
             n += 1
             print(f"[{time.time() - t0:6.1f}s] {desc}  {'ok' if not bad else 'FAIL ' + str(bad)}", flush=True)
             if bad:

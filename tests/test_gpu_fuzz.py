@@ -20,7 +20,7 @@ def test_random_problems_match_the_interpreter(name):
     rng = np.random.default_rng(1000 + list(SPECS).index(name))
     hip, interp = PF.get_backend(), InterpBackend()
     for c in range(4):
-        desc, bad = one_case(name, rng, dev, hip, interp, quad=(c % 2 == 1))
+        desc, bad = one_case(name, rng, dev, hip, interp, quad=(c % 2 == 1), whole=(c == 2))
         assert not bad, (desc, bad)
 
 
