@@ -613,11 +613,13 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   float wnext[P::NE];      // weights are fetched one step ahead so that their latency hides behind a step
 #pragma unroll
   for (int k = 0; k < P::NE; ++k) wnext[k] = ldc(a.wt, k * g.TR + min(max(n0 - 1, 0), g.TR - 1));
-  // Loss sums of this lane: fp32 (non-negative terms, a few points per step over the frames of one chunk); the
-  // workgroup's and every later reduction are fp64.
+  // Loss sums of this lane: fp32 over runs of 16 steps (non-negative terms, a few points per step), handed to an fp64
+  // sum at the end of every run, so that the error does not grow with the length of a clip; the workgroup's and every
+  // later reduction are fp64.
   float lsum[P::NE];
+  double lsum64[P::NE];
 #pragma unroll
-  for (int k = 0; k < P::NE; ++k) lsum[k] = 0.0f;
+  for (int k = 0; k < P::NE; ++k) { lsum[k] = 0.0f; lsum64[k] = 0.0; }
 
   // Frames are fetched two steps before the step that needs them in LDS: the loads of frame n+3 are issued
   // at the top of step n into one of two register sets and written to the ring at the end of step n+1, so a
@@ -723,6 +725,10 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
     if (WITH_LOSS) {
 #pragma unroll
       for (int k = 0; k < P::NE; ++k) lsum[k] = fmaf(lpart[k], wl[k], lsum[k]);
+      if ((n & 15) == 15) {      // uniform over the workgroup
+#pragma unroll
+        for (int k = 0; k < P::NE; ++k) { lsum64[k] += (double)lsum[k]; lsum[k] = 0.0f; }
+      }
     }
     PDE_AMD_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
@@ -835,9 +841,8 @@ __global__ __launch_bounds__((QuadCfg<P, W>::NTB), (QuadCfg<P, W>::WPS)) void bw
   }
   if (WITH_LOSS) {
     __syncthreads();
-    double lsum64[P::NE];
 #pragma unroll
-    for (int k = 0; k < P::NE; ++k) lsum64[k] = (double)lsum[k];
+    for (int k = 0; k < P::NE; ++k) lsum64[k] += (double)lsum[k];
     block_sum_store<P::NE, NT>(lsum64, s_red, a.partial + (long)w * P::NE);
   }
 }
