@@ -301,12 +301,21 @@ def main(argv=None):
     # first timed step walks code that no step before it has run (the library's timer entry point, the event hand-over).
     for a, b in backend.backward_event_pool + backend.forward_event_pool:
         a.record(); b.record()
-    for _ in range(2):
-        scratch_b, scratch_f = [], []
-        backend.backward_events, backend.forward_events = scratch_b, (None if args.mode == "fused" else scratch_f)
-        loss_step(0)
-        backend.backward_events = backend.forward_events = None
+
+    def run(k_steps):
+        """what the timed region runs: the steps, then the scalars of the last, unfinished window"""
+        for i in range(k_steps):
+            step(i)
+        win.flush(k_steps)
+        return win.drain()
+
+    # A rehearsal of the timed region, untimed: in a fresh process the first pass through any code path pays for what is
+    # loaded on first use (kernels of the few torch operations of the window hand-over, the probes' event path), which in a
+    # region of a few milliseconds is not noise (measured on a fresh box: 0.131-0.140 ms per step at 20 steps without it,
+    # 0.117 with).
+    run(min(args.steps, probe + 2 * window))
     torch.cuda.synchronize()
+    bwd_events.clear(); fwd_events.clear()
     # A few dozen 0.15 ms steps do not bring an idle GPU up to its working clocks (the same kernel measures 10 % slower in
     # the first milliseconds of activity): more untimed steps of the very same kind, until settle-ms have passed.
     settle_steps = 0
@@ -325,10 +334,7 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    win.flush(args.steps)
-    red = {k: v[-1] for k, v in win.drain()[-1][1].items()}      # the last step's scalars, mean over the ranks
+    red = {k: v[-1] for k, v in run(args.steps)[-1][1].items()}      # the last step's scalars, mean over the ranks
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
