@@ -275,9 +275,10 @@ def main(argv=None):
             torch.cuda.synchronize()
     graph = graphs[0] if graphs else None
     # an eager probe step costs more than a replayed one (the host cannot keep up), so only every 10th step is one
-    probe = 10 if args.steps >= 10 else max(2, args.steps // 2)
+    probe = 10 if args.steps >= 10 else max(1, args.steps // 2)
     if n_sets > 1 and probe % n_sets == 0:
         probe += 1                       # the probes visit every input set in turn
+    probe = max(1, min(probe, args.steps))      # at least one probe, however few steps
     n_probe = (args.steps + probe - 1) // probe
     pool = lambda n: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n + 2)]
     bwd_events, fwd_events = [], []
