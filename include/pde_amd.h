@@ -113,8 +113,9 @@ int pde_amd_residual_forward_backward(const pde_amd_problem* prob,
  * no allocation of any kind.  Problems with pde_amd_residual_workspace_bytes(prob) above that size are rejected with
  * PDE_AMD_ESCRATCH (every configuration of the reference's trainers fits: the largest, shear flow at B = 64, needs
  * 3.5 MiB).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
- * calls on one stream, or otherwise ordered, do not.  The first call on a device looks the array's address up
- * (hipGetSymbolAddress), so make it outside stream capture. */
+ * calls on one stream, or otherwise ordered, do not.  The array used is the one of the GPU that owns grads[0] (the
+ * current device where the runtime cannot tell), whichever device is current.  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress), so make it outside stream capture. */
 #define PDE_AMD_STATIC_SCRATCH_BYTES 4194304
 int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob,
                                              const float* const* fields, const float* const* aux,

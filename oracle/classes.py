@@ -264,12 +264,12 @@ def _batched(*fs):
     return tuple(f.unsqueeze(0) if f.dim() == 3 else f for f in fs)
 
 
-# the spectral legacy classes :28-146, :309-393 (a 3-D input is one sample)
+# the spectral legacy classes :28-146, :309-393 (the first adds a batch axis to a 3-D input, :101-104; the second never does)
 _mk("ActiveMatterPDELoss", ("continuity", "advection"), dict(nx=256, ny=256, dx=10.0 / 256, dy=10.0 / 256, dt=1.0),
     lambda s, c, u, v, reduction="mean": s.finish(O.residuals_active_matter_fft(*_batched(c, u, v), dx=s.kw["dx"], dy=s.kw["dy"], dt=s.kw["dt"]),
                                                   reduction=reduction), total_key=True)
 _mk("ViscoelasticContinuityLoss", ("continuity",), dict(nx=512, ny=512, dx=TWO_PI / 512, dy=2.0 / 512),
-    lambda s, u, v, reduction="mean": s.finish(O.residuals_viscoelastic_cont(*_batched(u, v), dx=s.kw["dx"], dy=s.kw["dy"]), reduction=reduction),
+    lambda s, u, v, reduction="mean": s.finish(O.residuals_viscoelastic_cont(u, v, dx=s.kw["dx"], dy=s.kw["dy"]), reduction=reduction),      # no batch axis is added (:352-389)
     total_key=True)
 
 

@@ -173,10 +173,23 @@ struct Ops {
     return (long)cdiv(p->n[0], P::FT0) * cdiv(p->n[1], P::FT1) * cdiv(p->n[2], P::FT2);
   }
 
+  // Most partial sums any forward tiling leaves per sample and residual frame: the 3-D tiles, or the plane-marching
+  // kernel's (y, x) tiles times its chunks of planes (never shorter than 8 planes: pick_plane_chunk), which outnumber
+  // the 3-D tiles on thin grids.
+  static long max_items_per_frame(const pde_amd_problem* p) {
+    long m = fwd_tiles(p);
+    if constexpr (ZCfg<P, P::ZW>::FWD_OK) {
+      using C = ZCfg<P, P::ZW>;
+      const long zm = (long)cdiv(p->n[0], p->n[0] < 8 ? p->n[0] : 8) * cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
+      if (zm > m) m = zm;
+    }
+    return m;
+  }
+
   static size_t ws_bytes(const pde_amd_problem* p) {
     const long tr = p->frames - P::TLO - P::THI;
     if (tr <= 0) return 256;
-    return (size_t)(p->batch * tr * fwd_tiles(p)) * P::NE * sizeof(double) + 256;
+    return (size_t)(p->batch * tr * max_items_per_frame(p)) * P::NE * sizeof(double) + 256;
   }
 
   static void fill_args(Args& a, const pde_amd_problem* p, const float* const* fields, const float* const* aux,
@@ -211,6 +224,9 @@ struct Ops {
     a.wt = weights;
     a.partial = reinterpret_cast<double*>(ws);
     const long tiles = fwd_tiles(p);
+    // partial sums per sample the workspace holds (the caller may have passed more than ws_bytes(p); the bound used here
+    // is the one ws_bytes promises)
+    const long cap = tr * max_items_per_frame(p);
     long items = 0;   // partial sums per sample
     if (resid_out) {
       for (int k = 0; k < P::NE; ++k) {
@@ -220,8 +236,8 @@ struct Ops {
       bool launched = false;
       if constexpr (ZFWD) {
         if (p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NE, P::ZW>(resid_out)) {
-          items = launch_plane_forward<true>(p, a, tr, stream);
-          if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+          items = launch_plane_forward<true>(p, a, tr, cap, stream);
+          if (items == -2) return PDE_AMD_EWORKSPACE;
           if (items < 0) return PDE_AMD_ESHAPE;
           launched = true;
         }
@@ -256,8 +272,8 @@ struct Ops {
       }
     } else if (ZFWD && p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields)) {
       if constexpr (ZFWD) {
-        items = launch_plane_forward<false>(p, a, tr, stream);
-        if (items > tr * tiles) return PDE_AMD_EWORKSPACE;
+        items = launch_plane_forward<false>(p, a, tr, cap, stream);
+        if (items == -2) return PDE_AMD_EWORKSPACE;
         if (items < 0) return PDE_AMD_ESHAPE;
       }
     } else if (QuadCfg<P, P::QWF>::FWD_OK && quad_addressable(p) && p->n[2] % P::QWF == 0 && aligned_vec<P::NF, P::QWF>(fields) &&
@@ -296,9 +312,10 @@ struct Ops {
     return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
   }
 
-  // Plane-marching forward of a 3-D PDE; returns the partial sums per sample (< 0: too many workgroups).
+  // Plane-marching forward of a 3-D PDE; returns the partial sums per sample (-1: too many workgroups; -2: more partial
+  // sums than `cap`, the number the workspace holds; nothing is launched in either case).
   template <bool WRITE_R>
-  static long launch_plane_forward(const pde_amd_problem* p, Args& a, long tr, hipStream_t stream) {
+  static long launch_plane_forward(const pde_amd_problem* p, Args& a, long tr, long cap, hipStream_t stream) {
     if constexpr (ZCfg<P, P::ZW>::FWD_OK) {
       using C = ZCfg<P, P::ZW>;
       const long yx = (long)cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
@@ -306,6 +323,7 @@ struct Ops {
       fill_geom(p, a.geo, a.chunk, C::T1, C::T2);
       const long items = tr * a.geo.nt0 * yx;
       if (p->batch * items >= (1L << 31)) return -1;
+      if (items > cap) return -2;
       hipLaunchKernelGGL((fwd_zmarch_kernel<P, P::ZW, WRITE_R>), dim3((unsigned)(p->batch * items)), dim3(C::NT), 0, stream, a);
       return items;
     }
@@ -600,17 +618,26 @@ int pde_amd_residual_forward_f64(const pde_amd_problem* prob, const double* cons
                     static_cast<hipStream_t>(stream));
 }
 
-// The device address of `scratch` on the current GPU, looked up once per device (each GPU holds its own copy).
-static int static_scratch(void** out) {
+// The device address of `scratch` on the GPU that owns `device_ptr` (one of the call's own buffers; the current device when
+// the runtime cannot tell), looked up once per device with that device current: each GPU holds its own copy of the array.
+static int static_scratch(const void* device_ptr, void** out) {
   constexpr int kMaxDevices = 64;
   static void* ptrs[kMaxDevices] = {};
   static std::mutex mu;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return PDE_AMD_EHIP;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return PDE_AMD_EHIP;
+  int dev = cur;
+  hipPointerAttribute_t attr;
+  if (device_ptr && hipPointerGetAttributes(&attr, device_ptr) == hipSuccess && attr.type == hipMemoryTypeDevice) dev = attr.device;
+  else (void)hipGetLastError();
+  if (dev < 0 || dev >= kMaxDevices) return PDE_AMD_EHIP;
   std::lock_guard<std::mutex> lock(mu);
   if (!ptrs[dev]) {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PDE_AMD_EHIP;
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) return PDE_AMD_EHIP;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (dev != cur && hipSetDevice(cur) != hipSuccess) return PDE_AMD_EHIP;
+    if (e != hipSuccess || !p) return PDE_AMD_EHIP;
     ptrs[dev] = p;
   }
   *out = ptrs[dev];
@@ -626,7 +653,8 @@ int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob, const 
   const size_t need = v->ws_bytes(prob);
   if (need > PDE_AMD_STATIC_SCRATCH_BYTES) return PDE_AMD_ESCRATCH;
   void* ws = nullptr;
-  const int st = static_scratch(&ws);
+  if (!grads || !grads[0]) return PDE_AMD_EINVAL;
+  const int st = static_scratch(grads[0], &ws);      // the GPU of the gradients, which is where the kernels write
   if (st) return st;
   // every partial sum the reduction reads is written by the kernel before it, so nothing has to be cleared between calls
   return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, ws,

@@ -682,6 +682,7 @@ int pde_amd_pair_stats_gather(const float* pred, const float* target, int64_t gr
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)workspace;
   if (gs.nf > 0 && rse_eps < 0.0f && tile_path_ok(gs.S, channels, pred, target) && TILE_PTS / channels >= 1 &&
+      (size_t)2 * TILE_PTS * channels * sizeof(float) <= 64 * 1024 &&      // two LDS images; wider tensors take the dword kernel's gather
       (size_t)NSTAT * TILE_PTS * sizeof(double) <= (size_t)2 * TILE_PTS * channels * sizeof(float)) {
     // one sweep with coalesced field writes; a sample's (frame, chunk) items are dealt to at most as many workgroups as the
     // workspace was sized for

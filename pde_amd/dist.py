@@ -141,7 +141,9 @@ class ScalarWindow:
         if self._filled:
             self._start(next_step - self._filled, self._filled)
             self._filled = 0
-        for h in ((next_step // self.steps + 1) % 2, (next_step // self.steps) % 2):      # older window first
+        # older window first: by the first step each pending half recorded (which half is the older one depends on
+        # whether the last window was a whole one)
+        for h in sorted((h for h in (0, 1) if self._pending[h] is not None), key=lambda h: self._pending[h][0]):
             self._finish(h)
 
     def drain(self) -> List[tuple]:

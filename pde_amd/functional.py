@@ -231,9 +231,32 @@ class HipBackend:
 _BACKEND = HipBackend()
 # Host path of residual_losses on the HIP backend: "op" = the C++ operator of libpde_amd_torch.so (default),
 # "ctypes" = the Python autograd function below over the ctypes binding (also used while launches are being timed)
-_HOST = os.environ.get("PDE_AMD_HOST", "op")
-if _HOST not in ("op", "ctypes"):
-    raise ValueError(f"PDE_AMD_HOST must be 'op' or 'ctypes', got {_HOST!r}")
+_HOST = os.environ.get("PDE_AMD_HOST", "auto")
+if _HOST not in ("auto", "op", "ctypes"):
+    raise ValueError(f"PDE_AMD_HOST must be 'auto', 'op' or 'ctypes', got {_HOST!r}")
+_OP_OK = None
+
+
+def _use_op() -> bool:
+    """Whether the residual losses go through the C++ operator.  'op' insists on it (and raises where the operator
+    library is missing or does not bind), 'ctypes' never uses it, 'auto' (default) uses it where it loads and otherwise
+    says so once and drives the same kernels from the Python autograd function.  The kernel library itself is required
+    either way."""
+    global _OP_OK
+    if _HOST == "ctypes":
+        return False
+    if _OP_OK is None:
+        try:
+            _lib.torch_op()
+            _OP_OK = True
+        except (RuntimeError, OSError) as e:
+            if _HOST == "op":
+                raise
+            _lib.lib()      # a missing kernel library is an error, not a reason to change the host path
+            import warnings
+            warnings.warn(f"pde_amd: the C++ torch operator is unavailable ({e}); using the Python autograd function over the same kernels")
+            _OP_OK = False
+    return _OP_OK
 _MODES = {"recompute": 0, "stored": 1, "fused": 2}
 
 
@@ -466,7 +489,7 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
     timed = be.backward_events is not None or be.forward_events is not None if type(be) is HipBackend else False
     fused_timed = timed and type(mode) is tuple and resolve_mode(mode[0], prob.spec) == "fused" and be.forward_events is None \
         and torch.is_grad_enabled() and any(f.requires_grad for f in fields)
-    if type(be) is HipBackend and _HOST == "op" and (not timed or fused_timed):
+    if type(be) is HipBackend and (not timed or fused_timed) and _use_op():
         assumed = None
         if type(mode) is tuple:
             mode, assumed = mode

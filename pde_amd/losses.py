@@ -873,9 +873,14 @@ class ViscoelasticContinuityLoss(StencilPDELoss):
         return torch.fft.irfft(1j * kh * torch.fft.rfft(f, dim=-2), n=f.shape[-2], dim=-2)
 
     def forward(self, u: Tensor, v: Tensor, reduction: str = "mean"):
-        if u.dim() == 3:
+        unbatched = u.dim() == 3      # [T, X, Y]: the reference never adds a batch axis (:352-389), so 'none' keeps that shape
+        if unbatched:
             u, v = u.unsqueeze(0), v.unsqueeze(0)
-        return self._evaluate([self.fft_dx(u.to(torch.float32)), v], reduction=reduction)
+        total, losses = self._evaluate([self.fft_dx(u.to(torch.float32)), v], reduction=reduction)
+        if unbatched and reduction == "none":
+            losses = {k: x.squeeze(0) for k, x in losses.items()}
+            total = total.squeeze(0)
+        return total, losses
 
 
 # =================================================================================================

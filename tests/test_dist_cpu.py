@@ -103,6 +103,66 @@ def _case_scalar_window(rank, world):
     return mine, got
 
 
+class _TrackedWindow(pdist.ScalarWindow):
+    """ScalarWindow that records which half of the buffer a collective owns, and every (first step, rows) it reduced."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.in_flight = set()
+        self.started = []
+
+    def _start(self, first, rows):
+        super()._start(first, rows)
+        h = (first // self.steps) % 2
+        assert h not in self.in_flight, "a half was handed to a second collective before the first was joined"
+        self.in_flight.add(h)
+        self.started.append((first, rows))
+
+    def _finish(self, h):
+        super()._finish(h)
+        self.in_flight.discard(h)
+
+
+def _case_replayed_window(rank, world):
+    """Rows written the way replayed graphs write them: one pre-built writer per residue of the step index, bound to a fixed
+    row address, knowing nothing of the window's state.  Windows of 4 over 14 and then 16 steps (a short last window and a
+    whole one): no row is written while a collective owns its half, no step is reduced twice, every step comes back."""
+    out = {}
+    for n in (14, 16):
+        win = _TrackedWindow(["a", "b"], steps=4, device="cpu", op="sum")
+        counter = [0]
+
+        def make_writer(res):
+            row = win.row(res)                 # captured once, like the pointer inside a graph
+            half = (res // win.steps) % 2
+
+            def replay():
+                assert half not in win.in_flight, "row overwritten while its window's all-reduce is in flight"
+                i = counter[0]
+                row.copy_(torch.tensor([float(i + 100 * rank), float(2 * i + 1000 * rank)]))
+            return replay
+
+        writers = [make_writer(res) for res in range(2 * win.steps)]
+        for i in range(n):
+            counter[0] = i
+            win.before(i)
+            writers[i % len(writers)]()
+            win.after(i)
+        win.flush(n)
+        assert not win.in_flight
+        firsts = [f for f, _ in win.started]
+        assert firsts == sorted(set(firsts)) and sum(r for _, r in win.started) == n      # each step in exactly one collective
+        done = win.drain()
+        assert [f for f, _ in done] == sorted(f for f, _ in done)                          # oldest first
+        got = {}
+        for first, vals in done:
+            for j in range(len(vals["a"])):
+                assert first + j not in got
+                got[first + j] = (float(vals["a"][j]), float(vals["b"][j]))
+        out[n] = got
+    return out
+
+
 def _case_accumulator(rank, world):
     from pde_amd import metrics as PM
     from pde_amd import reductions as R
@@ -216,6 +276,31 @@ def test_scalar_window_world2():
         for r in (0, 1):
             for x, y in zip(ret[r][1][i], want):
                 assert abs(x - y) <= 1e-6 * abs(y)
+
+
+def test_scalar_window_replayed_rows_world2():
+    _free_port.port = _free_port()
+    ret = _run(_case_replayed_window)
+    for r in (0, 1):
+        for n in (14, 16):
+            got = ret[r][n]
+            assert sorted(got) == list(range(n))
+            for i in range(n):
+                assert got[i] == (2.0 * i + 100.0, 4.0 * i + 1000.0), (n, i, got[i])      # sum over ranks 0 and 1, once
+
+
+def test_scalar_window_flush_after_whole_windows():
+    """flush when the step count is a multiple of the window: both pending halves come back, the older one first"""
+    for n in (8, 12, 16):
+        win = pdist.ScalarWindow(["a"], steps=4, device="cpu", op="sum")
+        for i in range(n):
+            win.before(i)
+            win.row(i).copy_(torch.tensor([float(i)]))
+            win.after(i)
+        win.flush(n)
+        done = win.drain()
+        assert [f for f, _ in done] == list(range(0, n, 4))
+        assert torch.cat([v["a"] for _, v in done]).tolist() == [float(i) for i in range(n)]
 
 
 def test_scalar_window_single_process():

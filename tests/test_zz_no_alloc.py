@@ -50,6 +50,36 @@ def test_static_scratch_step_matches_workspace_step():
             assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+def test_static_scratch_follows_the_buffers_not_the_current_device():
+    """buffers and stream on cuda:1 while cuda:0 is the current device: the scratch copy used is cuda:1's"""
+    dev = torch.device("cuda:1")
+    prob = StencilProblem("tg2d", list(_tg_consts()))
+    g = torch.Generator().manual_seed(6)
+    shape = (2, 6, 64, 128)
+    fields = [torch.randn(shape, generator=g).to(dev) for _ in range(3)]
+    nu = (0.01 + 0.09 * torch.rand(shape[0], generator=g)).to(dev)
+    weights = (0.5 + torch.rand(3, shape[1] - 2, generator=g)).to(dev)
+    ups = torch.tensor(0.75, device=dev)
+    with torch.cuda.device(dev):
+        st0, sums0, totals0, grads0 = _step(None, prob, fields, nu, weights, ups, static=False)
+    torch.cuda.set_device(0)
+    L = _lib.lib()
+    cp = prob.c_struct(shape)
+    sums = torch.full((shape[0], 3), -1.0, dtype=torch.float64, device=dev)
+    totals = torch.full((4,), -1.0, device=dev)
+    grads = [torch.full_like(f, float("nan")) for f in fields]
+    st = L.pde_amd_residual_forward_backward_static(
+        C.byref(cp), _lib.ptr_array(fields, 3), _lib.ptr_array([], 0), _lib.ptr_array([nu], 1), C.c_void_p(weights.data_ptr()),
+        C.c_void_p(ups.data_ptr()), C.c_void_p(sums.data_ptr()), C.c_void_p(totals.data_ptr()), _lib.ptr_array(grads, 3),
+        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize(dev)
+    assert st0 == 0 and st == 0
+    assert torch.equal(sums0, sums) and torch.equal(totals0, totals)
+    for a, b in zip(grads0, grads):
+        assert torch.equal(a, b)
+
+
 def test_static_scratch_rejects_oversized_problems():
     dev = torch.device("cuda:0")
     prob = StencilProblem("tg2d", list(_tg_consts()))

@@ -110,16 +110,21 @@ def cases():
     C["active_matter_fft_sum"] = ("ActiveMatterPDELoss", dict(nx=12, ny=10, dx=0.3, dy=0.25, dt=0.5), ["c", "u", "v"], S2, dict(reduction="sum"))
     C["viscoelastic_cont"] = ("ViscoelasticContinuityLoss", dict(nx=12, ny=10, dx=0.3, dy=0.25), ["u", "v"], S2, {})
     C["viscoelastic_cont_none"] = ("ViscoelasticContinuityLoss", dict(nx=12, ny=10, dx=0.3, dy=0.25), ["u", "v"], S2, dict(reduction="none"))
+    # [T, X, Y] inputs without a batch axis: the class never adds one, so reduction='none' returns [T, X, Y-2] fields
+    C["viscoelastic_cont_none_3d"] = ("ViscoelasticContinuityLoss", dict(nx=12, ny=10, dx=0.3, dy=0.25), ["u", "v"], (1, 5, 12, 10),
+                                      dict(reduction="none", __unbatched__=True))
     C["swift_hohenberg3d"] = ("SwiftHohenberg3DPDELoss", dict(domain_extent=6.0, num_points=6, dt=0.1), ["u"], S3, {})
     return C
 
 
 def run_case(name, spec, mod):
     cls_name, kwargs, fnames, shape, extra = spec
+    extra = dict(extra)
+    unbatched = extra.pop("__unbatched__", False)      # the fields are generated with a batch of one and handed over without it
     seed = abs(hash(name)) % 10000 if False else sum(ord(ch) for ch in name)
     out = {}
     for dt_name, dtype in (("f64", torch.float64), ("f32", torch.float32)):
-        fields = [f.to(dtype).requires_grad_(True) for f in _fields(shape, len(fnames), seed)]
+        fields = [(f[0] if unbatched else f).to(dtype).requires_grad_(True) for f in _fields(shape, len(fnames), seed)]
         kw = {}
         for k, v in extra.items():
             if isinstance(v, str) and v == "__c_field__":
@@ -142,7 +147,7 @@ def run_case(name, spec, mod):
         for k, v in d.items():
             out[f"{dt_name}_loss_{k}"] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
         for n, f in zip(fnames, fields):
-            out[f"{dt_name}_grad_{n}"] = f.grad.numpy() if f.grad is not None else np.zeros(shape)
+            out[f"{dt_name}_grad_{n}"] = f.grad.numpy() if f.grad is not None else np.zeros(tuple(f.shape))
 
     def jsonable(v):
         if torch.is_tensor(v):
