@@ -95,19 +95,95 @@ def cpu_baseline():
             "one_thread_value": one}
 
 
-def measured_traffic(kernel_substr):
-    """HBM-side bytes per launch of a kernel from the committed hardware-counter passes (tools/profile_round.sh):
-    2 x FETCH_SIZE + WRITE_SIZE, each collected in its own rocprofv3 --pmc run.  None when no measurement is on file."""
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` (its name as a profiler prints it, pde_amd_last_adjoint_kernel) from the committed
+    hardware-counter passes (tools/profile_round.sh): 2 x FETCH_SIZE + WRITE_SIZE, each collected in its own rocprofv3 --pmc
+    run.  A kernel without a measurement on file is an error: the figure must belong to the kernel that was timed."""
     path = os.path.join(ROOT, "pde_amd", "measured", "tg2d_traffic.json")
-    try:
-        with open(path) as fh:
-            data = json.load(fh)
-    except OSError:
-        return None
-    for name, rec in data.items():
-        if kernel_substr in name:
-            return rec["total_bytes"]
-    return None
+    with open(path) as fh:
+        data = json.load(fh)
+    if kernel not in data:
+        raise KeyError(f"bench: no HBM-traffic measurement on file for {kernel!r} in {path}; run tools/profile_round.sh and copy "
+                       f"its <tag>_traffic.json there (kernels on file: {sorted(data)})")
+    return data[kernel]["total_bytes"]
+
+
+def last_adjoint_kernel():
+    """the adjoint kernel of the last launch that was timed (the backend asks the library on the launching thread)"""
+    return PF.HipBackend.last_adjoint_kernel
+
+
+# The reference's other benchmark configurations, run after the timed region (they are not part of `value`): class,
+# constructor arguments, field shape, per-sample parameters.
+def other_case_table(dev):
+    U = lambda b, lo, hi: lo + (hi - lo) * torch.rand(b, device=dev)
+    return [
+        ("Rayleigh-Benard B=64, [64,9,512,128] x3", "RayleighBenardFullPDELoss", {}, (64, 9, 512, 128), lambda b: dict(kappa=U(b, 1e-4, 1e-2))),
+        ("shear flow n-PINN B=64, [64,9,256,512] x4", "ShearFlowPDELossNPINN", {}, (64, 9, 256, 512), lambda b: {}),
+        ("Gray-Scott FD-c4, 8 samples per GPU, [8,9,128,128] x2", "GrayScottPDELoss", dict(laplacian="fd4"), (8, 9, 128, 128), lambda b: {}),
+        ("Gray-Scott FFT Laplacian, 8 samples per GPU, [8,9,128,128] x2", "GrayScottPDELoss", {}, (8, 9, 128, 128), lambda b: {}),
+        ("heat 3-D B=2, [2,9,128,128,128] x1", "Heat3DPDELoss", {}, (2, 9, 128, 128, 128), lambda b: dict(alpha=U(b, 0.005, 0.05))),
+        ("APEBench Burgers 3-D B=1, [1,9,128,128,128] x3", "APEBenchBurgers3DPDELoss", dict(nx=128), (1, 9, 128, 128, 128), lambda b: {}),
+    ]
+
+
+def run_other_cases(dev, launches=16):
+    """fwd+bwd of each other configuration through the nn.Module API in 'fused' mode (which resolves to the fastest measured
+    kernels of each PDE): step time from events around whole steps, the adjoint kernel's launch time from events the library
+    records around that launch, its name from the library, frac = 8 E_in / time / 8 TB/s (read every field once, write
+    every gradient once)."""
+    import inspect
+    backend = PF.get_backend()
+    out = []
+    for tag, cls_name, kw, shape, params in other_case_table(dev):
+        mod = getattr(pde_amd, cls_name)(**kw).to(dev)
+        mod.backward_mode = "fused"
+        names = set(params(1))
+        nf = sum(1 for q in inspect.signature(mod.forward).parameters.values() if q.default is inspect.Parameter.empty and q.name not in names)
+        gen = torch.Generator(device=dev).manual_seed(4321)
+        fields = [(0.5 * torch.randn(shape, device=dev, generator=gen)).requires_grad_(True) for _ in range(nf)]
+        pk = params(shape[0])
+
+        def step():
+            for f in fields:
+                f.grad = None
+            total, _ = mod(*fields, **pk)
+            total.backward()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < 100.0:      # working clocks
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for a, b in evs:
+            a.record(); step(); b.record()
+        torch.cuda.synchronize()
+        step_ms = sorted(a.elapsed_time(b) for a, b in evs)[launches // 2]
+        kev = []
+        backend.backward_events, backend.forward_events = kev, None
+        try:
+            for _ in range(launches):
+                step()
+        finally:
+            backend.backward_events = backend.forward_events = None
+        torch.cuda.synchronize()
+        k_ms = sorted(a.elapsed_time(b) for a, b in kev)
+        e_in = nf
+        for v in shape:
+            e_in *= v
+        rec = {"workload": tag, "ms_per_step": step_ms, "backward_mode": PF.resolve_mode("fused", mod.SPEC, fields[0].numel()),
+               "kernel": last_adjoint_kernel(), "algorithmic_bytes": 8 * e_in, "timed_launches": len(k_ms)}
+        if k_ms:
+            avg = sum(k_ms) / len(k_ms)
+            rec.update(avg_ms=avg, frac=8 * e_in / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        out.append(rec)
+        del fields, mod
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_command(gpus, argv, port, python=None):
@@ -137,6 +213,11 @@ def parse_args(argv=None):
                          "gradients) exceed the 256 MiB Infinity Cache, so every step reads its fields from HBM ('cold'); "
                          "1 = the same 201 MB every step ('warm')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="leave roofline.traffic null instead of looking the kernel's counter measurement up (the profiling runs "
+                         "that produce that measurement use this)")
+    ap.add_argument("--no-other-cases", action="store_true",
+                    help="skip the sweep over the reference's other benchmark configurations after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--mode", default="fused", choices=["fused", "auto"],
                     help="loss module backward_mode: 'fused' = loss and gradient in one pass of the adjoint kernel (it recomputes "
@@ -350,6 +431,15 @@ def main(argv=None):
     value = pts_per_rank * world / (elapsed / args.steps)
 
     if rank == 0:
+        # more cold launches for the kernel figure than the few probes inside the timed region: eager steps that keep cycling
+        # through the input sets (every launch reads fields the caches have since lost), events around the adjoint launch only
+        if n_sets > 1:
+            backend.backward_events, backend.forward_events = bwd_events, (None if args.mode == "fused" else fwd_events)
+            for j in range(max(0, 24 - len(bwd_events))):
+                loss_step((args.steps + j) % n_sets)
+            backend.backward_events = backend.forward_events = None
+            torch.cuda.synchronize()
+        kernel_name = last_adjoint_kernel()
         k_ms = sorted(x.elapsed_time(y) for x, y in bwd_events)
         f_ms = sorted(x.elapsed_time(y) for x, y in fwd_events)      # empty in fused mode: there is no forward launch
         bwd_avg = sum(k_ms) / len(k_ms)                   # the adjoint kernel launch alone
@@ -385,16 +475,20 @@ def main(argv=None):
                        "logging": f"the step's loss scalars of {window} steps share one all-reduce (mean over the ranks), started "
                                   f"when the window closes and joined a window later" if window > 1 else
                                   "one all-reduce of the step's loss scalars per step, joined a step later"},
-            "roofline": {"bound": "hbm", "kernel": "bwd_march_q_kernel<Pde_tg2d> (the adjoint; one launch per step; HIP events recorded by "
-                                                     "the library on the launch stream right before and after that launch" +
-                                                     ("; in fused mode the kernel also sums the loss)" if args.mode == "fused" else ")"),
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
+                         "kernel_note": "the adjoint; one launch per step; HIP events recorded by the library on the launch stream right "
+                                        "before and after that launch" + ("; in fused mode the kernel also sums the loss" if args.mode == "fused" else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("bwd_march_q_kernel<pde_amd::Pde_tg2d, 4, true>" if args.mode == "fused" else "bwd_march_q_kernel<pde_amd::Pde_tg2d, 4>"), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
+                         "traffic": None if args.no_traffic else measured_traffic(kernel_name), "algorithmic_bytes": bwd_bytes, "avg_ms": bwd_avg,
                          "median_ms": k_ms[len(k_ms) // 2], "timed_launches": len(k_ms), "cache": cache, **other,
                          **({"fwd_median_ms": f_ms[len(f_ms) // 2], "fwd_algorithmic_bytes": 4 * e_in,
-                             "fwd_traffic": measured_traffic("fwd_march_q_kernel")} if f_ms else {})},
+                             } if f_ms else {})},
             "loss": float(red["total"]),
         }
+        if world > 1 or distributed:
+            out["rccl_world_size"] = dist.get_world_size()
+        if world == 1 and not args.no_other_cases:
+            out["other_cases"] = run_other_cases(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -133,12 +133,16 @@ int pde_amd_residual_forward_f64(const pde_amd_problem* prob, const double* cons
                                  const double* const* aux, const double* const* sparams, const double* weights, double* sums,
                                  double* totals, double* const* resid_out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Measurement hook, no counterpart in the reference: the next launch of the register-blocked adjoint kernel issued from
- * this host thread (by pde_amd_residual_backward in recompute mode or by pde_amd_residual_forward_backward) records the
- * two HIP events (hipEvent_t, created with timing enabled) on its stream immediately before and after that one launch;
- * the small reduction launches of the same call stay outside.  One-shot: the events are forgotten afterwards, also when
- * the call took another kernel.  NULL, NULL disarms it. */
+/* Measurement hook, no counterpart in the reference: the next launch of an adjoint kernel issued from this host thread
+ * (by pde_amd_residual_backward in either mode, or by pde_amd_residual_forward_backward) records the two HIP events
+ * (hipEvent_t, created with timing enabled) on its stream immediately before and after that one launch; the small
+ * reduction launches of the same call stay outside.  One-shot: the events are forgotten afterwards.  NULL, NULL disarms it. */
 int pde_amd_time_next_adjoint(void* start_event, void* stop_event);
+
+/* The adjoint kernel the last backward or one-pass call of this host thread launched, spelled as a profiler prints it
+ * (e.g. "bwd_march_q_kernel<pde_amd::Pde_tg2d, 4, true, true>"): the key under which a measurement of that kernel is
+ * filed.  "" before the first such call.  The string lives in thread-local storage of the library. */
+const char* pde_amd_last_adjoint_kernel(void);
 
 /* grads[f][i] *= *upstream / *assumed for n_fields arrays of `elements` floats; nothing is read or written when the
  * two device scalars are equal (decided on the device, no host synchronisation).  It turns the gradients that

@@ -3,8 +3,10 @@
 #include "stencil_kernels.hpp"
 #include "stencil_quad.hpp"
 #include "stencil_zmarch.hpp"
+#include "stencil_zcol.hpp"
 #include "stencil_f64.hpp"
 #include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
 
@@ -70,6 +72,11 @@ struct AdjointTimer {
     if (e1 && hipEventRecord(e1, st) != hipSuccess) { t_ev_failed = true; (void)hipGetLastError(); }
   }
 };
+// Name of the adjoint kernel the last backward / one-pass call on this host thread launched, as a profiler prints it.
+static thread_local char t_kernel[192] = "";
+static void note_kernel(const char* base, const char* pde, const char* targs) {
+  snprintf(t_kernel, sizeof(t_kernel), "%s<pde_amd::Pde_%s%s>", base, pde, targs);
+}
 // status of a call whose launches are done: a failed launch first, then a failed timing-event record
 static inline int launch_status() {
   const bool ev = t_ev_failed;
@@ -183,7 +190,58 @@ struct Ops {
       const long zm = (long)cdiv(p->n[0], p->n[0] < 8 ? p->n[0] : 8) * cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
       if (zm > m) m = zm;
     }
+    if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {      // at most one frame group per residual frame
+      using C = ZColCfg<P, P::ZCW>;
+      const long zm = (long)cdiv(p->n[0], p->n[0] < 8 ? p->n[0] : 8) * cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
+      if (zm > m) m = zm;
+    }
     return m;
+  }
+
+  // z-column kernels: frames per workgroup, planes per chunk (a chunk re-reads 2 * reach planes: as long as still gives
+  // every CU a workgroup, never shorter than 8 planes), geometry; returns the number of workgroups per sample
+  template <int LPF_, int FPW_, int T1_, int T2_>
+  static long plan_zcol(const pde_amd_problem* p, Args& a, long tr, int& nfw) {
+    const long ngroups = cdiv((int)tr, FPW_);
+    nfw = cdiv((int)tr, (int)ngroups);      // groups of equal length, up to one frame
+    const long yx = (long)cdiv(p->n[1], T1_) * cdiv(p->n[2], T2_);
+    const long blocks = p->batch * ngroups * yx;
+    int nchunk = (int)((256 + blocks - 1) / blocks);
+#ifdef PDE_AMD_DIAG_ONLY
+    if (getenv("PDE_AMD_ZCHUNK")) nchunk = cdiv(p->n[0], atoi(getenv("PDE_AMD_ZCHUNK")));
+#endif
+    if (nchunk < 1) nchunk = 1;
+    int chunk = cdiv(p->n[0], nchunk);
+    if (chunk < 8) chunk = p->n[0] < 8 ? p->n[0] : 8;
+    a.chunk = chunk;
+    fill_geom(p, a.geo, chunk, T1_, T2_);
+    return ngroups * a.geo.nt0 * yx;
+  }
+
+  // -1: too many workgroups; -2: more partial sums than `cap`; -3: the kernel's LDS could not be granted
+  template <bool WRITE_R>
+  static long launch_zcol_forward(const pde_amd_problem* p, Args& a, long tr, long cap, hipStream_t stream) {
+    if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
+      using C = ZColCfg<P, P::ZCW>;
+      int nfw;
+      const long items = plan_zcol<C::LPF, C::FPWF, C::T1, C::T2>(p, a, tr, nfw);
+      if (p->batch * items >= (1L << 31)) return -1;
+      if (items > cap) return -2;
+      const size_t lds = C::fwd_lds(nfw);
+      auto kern = fwd_zcol_kernel<P, P::ZCW, WRITE_R>;
+      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return -3;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(p->batch * items)), dim3(C::LPF * nfw), lds, stream, a, nfw);
+      return items;
+    }
+    return -3;
+  }
+
+  template <int W = P::ZCW>
+  static bool zcol_usable(const pde_amd_problem* p, const float* const* fields) {
+    return p->n[2] % W == 0 && aligned_vec<P::NF, W>(fields) && (long)p->n[1] * p->n[2] < (1L << 30);
   }
 
   static size_t ws_bytes(const pde_amd_problem* p) {
@@ -228,14 +286,32 @@ struct Ops {
     // is the one ws_bytes promises)
     const long cap = tr * max_items_per_frame(p);
     long items = 0;   // partial sums per sample
-    if (resid_out) {
+    bool zc_done = false;      // the z-column forward without residual output ran
+    if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
+      if (!resid_out && P::ZCOLV != 0 && zcol_usable(p, fields)) {
+        items = launch_zcol_forward<false>(p, a, tr, cap, stream);
+        if (items == -2) return PDE_AMD_EWORKSPACE;
+        if (items == -1) return PDE_AMD_ESHAPE;
+        zc_done = items > 0;
+      }
+    }
+    if (zc_done) {
+    } else if (resid_out) {
       for (int k = 0; k < P::NE; ++k) {
         if (!resid_out[k]) return PDE_AMD_EINVAL;
         a.rout[k] = resid_out[k];
       }
       bool launched = false;
+      if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
+        if (zcol_usable(p, fields) && aligned_vec<P::NE, P::ZCW>(resid_out)) {
+          items = launch_zcol_forward<true>(p, a, tr, cap, stream);
+          if (items == -2) return PDE_AMD_EWORKSPACE;
+          if (items == -1) return PDE_AMD_ESHAPE;
+          launched = items > 0;
+        }
+      }
       if constexpr (ZFWD) {
-        if (p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NE, P::ZW>(resid_out)) {
+        if (!launched && p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NE, P::ZW>(resid_out)) {
           items = launch_plane_forward<true>(p, a, tr, cap, stream);
           if (items == -2) return PDE_AMD_EWORKSPACE;
           if (items < 0) return PDE_AMD_ESHAPE;
@@ -401,10 +477,13 @@ struct Ops {
         if (nwg < (1L << 31) && (size_t)nwg * P::NE * sizeof(double) <= ws_bytes_given) {
           {
             AdjointTimer timer(stream);
-            if (full_grid(p))
+            if (full_grid(p)) {
               hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
-            else
+              note_kernel("bwd_march_q_kernel", P::NAME, P::QWB == 2 ? ", 2, true, true" : ", 4, true, true");
+            } else {
               hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), 0, stream, a);
+              note_kernel("bwd_march_q_kernel", P::NAME, P::QWB == 2 ? ", 2, true" : ", 4, true");
+            }
           }
           reduce_partials(a.partial, sums, totals, items, p->batch, stream);
           fused = true;
@@ -454,8 +533,30 @@ struct Ops {
         a.r[k] = resid_in[k];
       }
       bool launched = false;
+      AdjointTimer timer(stream);
+      if constexpr (ZColCfg<P, P::ZCWB>::BWD_OK) {
+        if (zcol_usable<P::ZCWB>(p, fields) && aligned_vec<P::NF, P::ZCWB>(grads) && aligned_vec<P::NE, P::ZCWB>(resid_in)) {
+          using C = ZColCfg<P, P::ZCWB>;
+          int nfw;
+          const long items = plan_zcol<C::LPF, C::FPWB, C::T1, C::T2>(p, a, tr, nfw);
+          if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
+          const size_t lds = C::bwd_lds(nfw);
+          const bool multi = tr > nfw;
+          auto kern = multi ? bwd_stored_zcol_kernel<P, P::ZCWB, true> : bwd_stored_zcol_kernel<P, P::ZCWB, false>;
+          bool ok = true;
+          if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+          }
+          if (ok) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p->batch * items)), dim3(C::LPF * nfw), lds, stream, a, nfw);
+            note_kernel("bwd_stored_zcol_kernel", P::NAME, P::ZCWB == 2 ? (multi ? ", 2, true" : ", 2, false") : (multi ? ", 4, true" : ", 4, false"));
+            launched = true;
+          }
+        }
+      }
       if constexpr (ZCfg<P, P::ZW>::BWD_OK) {
-        if (p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NF, P::ZW>(grads) && aligned_vec<P::NE, P::ZW>(resid_in)) {
+        if (!launched && p->n[2] % P::ZW == 0 && aligned_vec<P::NF, P::ZW>(fields) && aligned_vec<P::NF, P::ZW>(grads) && aligned_vec<P::NE, P::ZW>(resid_in)) {
           using C = ZCfg<P, P::ZW>;
           const long yx = (long)cdiv(p->n[1], C::T1) * cdiv(p->n[2], C::T2);
           a.chunk = pick_plane_chunk(p->batch * p->frames * yx, p->n[0]);
@@ -463,6 +564,7 @@ struct Ops {
           const long nwgz = (long)p->batch * p->frames * a.geo.nt0 * yx;
           if (nwgz >= (1L << 31)) return PDE_AMD_ESHAPE;
           hipLaunchKernelGGL((bwd_stored_zmarch_kernel<P, P::ZW>), dim3((unsigned)nwgz), dim3(C::NT), 0, stream, a);
+          note_kernel("bwd_stored_zmarch_kernel", P::NAME, P::ZW == 2 ? ", 2" : ", 4");
           launched = true;
         }
       }
@@ -474,6 +576,7 @@ struct Ops {
           const long nwgq = (long)p->batch * p->frames * a.geo.nt0 * a.geo.nt1 * a.geo.nt2;
           if (nwgq >= (1L << 31)) return PDE_AMD_ESHAPE;
           hipLaunchKernelGGL((bwd_stored_q_kernel<P, P::QWB>), dim3((unsigned)nwgq), dim3(StoredCfg<P, P::QWB>::NT), 0, stream, a);
+          note_kernel("bwd_stored_q_kernel", P::NAME, P::QWB == 2 ? ", 2" : ", 4");
           launched = true;
         }
       }
@@ -481,6 +584,7 @@ struct Ops {
         const long nwg = (long)p->batch * p->frames * tiles;
         if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
         hipLaunchKernelGGL((bwd_stored_kernel<P>), dim3((unsigned)nwg), dim3(P::NT), 0, stream, a);
+        note_kernel("bwd_stored_kernel", P::NAME, "");
       }
     } else if (QuadCfg<P, P::QWB>::BWD_OK && quad_addressable(p) && p->n[2] % P::QWB == 0 && aligned_vec<P::NF, P::QWB>(fields) &&
                aligned_vec<P::NF, P::QWB>(grads) && (!P::NA || aligned_vec<P::NA, P::QWB>(aux))) {
@@ -496,17 +600,22 @@ struct Ops {
         constexpr int dyn_lds = 0;
 #endif
         AdjointTimer timer(stream);
-        if (full_grid(p))
+        if (full_grid(p)) {
           hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB, false, true>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
-        else
+          note_kernel("bwd_march_q_kernel", P::NAME, P::QWB == 2 ? ", 2, false, true" : ", 4, false, true");
+        } else {
           hipLaunchKernelGGL((bwd_march_q_kernel<P, P::QWB>), dim3((unsigned)nwg), dim3(QuadCfg<P, P::QWB>::NTB), dyn_lds, stream, a);
+          note_kernel("bwd_march_q_kernel", P::NAME, P::QWB == 2 ? ", 2" : ", 4");
+        }
       }
     } else {
       if constexpr (BwdMarchFits<P>::value) {
         a.chunk = pick_chunk(p->batch * tiles, p->frames);
         const long nwg = (long)p->batch * cdiv(p->frames, a.chunk) * tiles;
         if (nwg >= (1L << 31)) return PDE_AMD_ESHAPE;
+        AdjointTimer timer(stream);
         hipLaunchKernelGGL((bwd_march_kernel<P>), dim3((unsigned)nwg), dim3(P::NTM), 0, stream, a);
+        note_kernel("bwd_march_kernel", P::NAME, "");
       } else {
         return PDE_AMD_EINVAL;   // this PDE has no recomputing adjoint: pass the stored residuals
       }
@@ -660,6 +769,31 @@ int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob, const 
   return v->fwd_bwd(prob, fields, aux, sparams, weights, upstream_total, sums, totals, grads, ws,
                     PDE_AMD_STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream));
 }
+
+const char* pde_amd_last_adjoint_kernel(void) { return t_kernel; }
+
+#ifdef PDE_AMD_DIAG_ONLY
+// diagnostic builds only: workgroups per CU the runtime grants the z-column kernels of the build's PDE
+void pde_amd_diag_zcol_occupancy(void) {
+  using P = PDE_AMD_DIAG_ONLY;
+  if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
+    using C = ZColCfg<P, P::ZCW>;
+    for (int nfw = 1; nfw <= C::FPWF; ++nfw) {
+      int n = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fwd_zcol_kernel<P, P::ZCW, true>, C::LPF * nfw, C::fwd_lds(nfw));
+      printf("fwd_zcol nfw=%d threads=%d lds=%zu -> %d workgroups per CU (%s)\n", nfw, C::LPF * nfw, C::fwd_lds(nfw), n, hipGetErrorString(e));
+    }
+  }
+  if constexpr (ZColCfg<P, P::ZCWB>::BWD_OK) {
+    using C = ZColCfg<P, P::ZCWB>;
+    for (int nfw = 1; nfw <= C::FPWB; ++nfw) {
+      int n = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bwd_stored_zcol_kernel<P, P::ZCWB, false>, C::LPF * nfw, C::bwd_lds(nfw));
+      printf("bwd_zcol nfw=%d threads=%d lds=%zu -> %d workgroups per CU (%s)\n", nfw, C::LPF * nfw, C::bwd_lds(nfw), n, hipGetErrorString(e));
+    }
+  }
+}
+#endif
 
 int pde_amd_time_next_adjoint(void* start_event, void* stop_event) {
   t_ev0 = static_cast<hipEvent_t>(start_event);

@@ -17,6 +17,7 @@
 namespace pde_amd {
 
 template <int W> struct VecOf;
+template <> struct VecOf<1> { typedef float type __attribute__((ext_vector_type(1))); };
 template <> struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
 

@@ -73,6 +73,7 @@ class HipBackend:
     backward_event_pool = None       # optional list of pre-created (start, end) event pairs to draw from
     forward_events = None            # same for the forward launches (residual kernel + the two tiny reductions)
     forward_event_pool = None
+    last_adjoint_kernel = ""         # with backward_events set: the adjoint kernel of the last timed call, as a profiler names it
 
     @staticmethod
     def _stream(t: torch.Tensor):
@@ -109,7 +110,11 @@ class HipBackend:
 
     def _disarm_adjoint_timer(self, ev):
         if ev is not None:
-            _lib.lib().pde_amd_time_next_adjoint(None, None)
+            L = _lib.lib()
+            L.pde_amd_time_next_adjoint(None, None)
+            # asked here, on the thread that made the call (autograd runs backward on a thread of its own, and the library
+            # keeps the name per thread)
+            HipBackend.last_adjoint_kernel = L.pde_amd_last_adjoint_kernel().decode()
             self.backward_events.append(ev)
 
     def can_recompute(self, spec: str) -> bool:
@@ -304,19 +309,28 @@ def get_backend():
     return _BACKEND
 
 
-def resolve_mode(mode: str, spec: str) -> str:
+# Fields of fewer elements than this take the per-frame stored-residual kernels in 'auto' and 'fused': a marching kernel
+# walks a clip's frames one after the other, and on a problem this small the chip has too few workgroups to hide that
+# chain (Gray-Scott FD-c4 at 8 samples, [8, 9, 128, 128]: stored 0.062 ms, recompute 0.085, one pass 0.081).
+SMALL_FIELD_ELEMENTS = 2_000_000
+
+
+def resolve_mode(mode: str, spec: str, field_elements: Optional[int] = None) -> str:
     """'auto' and 'fused' -> the kernels that run: 'recompute' (forward kernel, then an adjoint that re-evaluates the
     residuals), 'stored' (forward writes the residuals, the adjoint reads them) or 'fused' (one pass).  'auto' recomputes
     where the PDE allows it, unless its spec says the stored kernels measured faster (`auto_stored`); 'fused' needs the
     recomputing adjoint and yields to what 'auto' takes where the spec says the one-pass step measured slower
-    (`fused_slower`)."""
+    (`fused_slower`).  Small problems (`field_elements`, the elements of one field, below SMALL_FIELD_ELEMENTS) take the
+    stored kernels in both."""
     if mode not in ("auto", "fused"):
         return mode
     if mode == "fused" and os.environ.get("PDE_AMD_FORCE_FUSED") == "1" and _BACKEND.can_recompute(spec):
-        return "fused"      # diagnostic: measure the one-pass step where the spec prefers other kernels (tools/mode_sweep.sh)
+        return "fused"      # diagnostic: measure the one-pass step where the spec prefers other kernels (tools/mode_sweep.py)
     s = SPECS[spec]
     can = _BACKEND.can_recompute(spec)
     if not can:
+        return "stored"
+    if field_elements is not None and field_elements < SMALL_FIELD_ELEMENTS and s.ndim > 1:
         return "stored"
     if mode == "fused" and not s.fused_slower:
         return "fused"
@@ -334,7 +348,7 @@ class _ResidualLosses(torch.autograd.Function):
         assumed = None
         if isinstance(mode, tuple):      # ('fused', device scalar): the upstream gradient of the total to assume
             mode, assumed = mode
-        mode = resolve_mode(mode, prob.spec)
+        mode = resolve_mode(mode, prob.spec, fields[0].numel())
         ctx.ghat = ctx.assumed = None
         if need_grad and mode == "fused":
             # loss and gradient in one pass; the gradient is handed out in backward, rescaled if autograd delivers
@@ -487,13 +501,13 @@ def residual_losses(prob: StencilProblem, fields: Sequence[torch.Tensor], weight
     # library records the events around that launch); the other modes launch their adjoint from autograd's thread, where
     # only the Python function can arm the timer.
     timed = be.backward_events is not None or be.forward_events is not None if type(be) is HipBackend else False
-    fused_timed = timed and type(mode) is tuple and resolve_mode(mode[0], prob.spec) == "fused" and be.forward_events is None \
+    fused_timed = timed and type(mode) is tuple and resolve_mode(mode[0], prob.spec, fields[0].numel()) == "fused" and be.forward_events is None \
         and torch.is_grad_enabled() and any(f.requires_grad for f in fields)
     if type(be) is HipBackend and (not timed or fused_timed) and _use_op():
         assumed = None
         if type(mode) is tuple:
             mode, assumed = mode
-        mode = resolve_mode(mode, prob.spec)
+        mode = resolve_mode(mode, prob.spec, fields[0].numel())
         ev = be._arm_adjoint_timer() if fused_timed else None
         try:
             out = _lib.torch_op()(fields, aux, sparams, weights, *prob.op_args(), _MODES[mode], assumed, getattr(_DEST, "vec", None))

@@ -13,7 +13,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field as dc_field
 from typing import Callable, Dict, List, Sequence, Tuple
 
-from .expr import E, Ref, GRef, adjoint_exprs, footprint
+from .expr import E, Ref, GRef, adjoint_exprs, collect, footprint
 from .ops import (Q, C2_D1, C2_D2, C4_D1, C4_D2, D4_5PT, KDV_D3, KDV_D4, aux, const, dt_central,
                   face_div, field, qpsel, qsel, sh, sparam, stencil, tsh, upwind_flux_div)
 
@@ -54,6 +54,12 @@ class Spec:
     z_threads: int = 256
     z_width: int = 2
     z_first: bool = False           # forward: prefer the plane-marching kernel to the time-marching one
+    # z-column kernels (csrc/stencil_zcol.hpp): a workgroup marches a (y, x) tile through z for a whole group of frames
+    zcol: bool = False              # stored-residual forward and adjoint take these kernels where the PDE qualifies
+    zcol_plain_fwd: bool = False    # ... and so does the forward that stores no residuals (measured per PDE)
+    zc_tile: Tuple[int, int] = (8, 32)
+    zc_width: int = 2               # points per lane of the forward ...
+    zc_width_bwd: int = 2           # ... and of the adjoint
     auto_stored: bool = False       # backward modes 'auto' and 'fused' take the stored-residual kernels although the PDE can recompute
     fused_slower: bool = False      # the one-pass step measured slower than forward + recomputing adjoint: 'fused' takes those
     hoist_uniforms: bool = True     # precompute products/sums of constants and per-sample parameters once per sample
@@ -69,6 +75,10 @@ class Spec:
         self.fp_adj_g = footprint(self.adjoint, GRef)
         self.tlo = -self.fp_res["tmin"]
         self.thi = self.fp_res["tmax"]
+        # every tap with an offset along axis 0 ("z") sits on the axis: no (y, x) offset, same frame
+        pure = lambda nodes: all(n.o[0] == 0 or (n.o[1] == 0 and n.o[2] == 0 and n.ot == 0) for n in nodes)
+        self.z_pure = self.ndim == 3 and pure([n for e in self.residuals for n in collect(e, Ref).values()]) and \
+            pure([n for e in self.adjoint for n in collect(e, GRef).values()])
         return self
 
 
@@ -240,7 +250,7 @@ def _wave2d():
     u, w = b.F()
     c2 = b.s("c2")
     lap = _d2c4(b, u, 1, "dx") + _d2c4(b, u, 2, "dy")
-    return b.done([_ddt(b, u) - w, _ddt(b, w) - c2 * lap])
+    return b.done([_ddt(b, u) - w, _ddt(b, w) - c2 * lap], fused_slower=True)      # [32, 9, 256^2]: one pass 0.095 ms, forward + recomputing adjoint 0.091
 
 
 def _ape_burgers2d():
@@ -429,7 +439,7 @@ def _gray_scott_fd():
     ab2 = A * Bq * Bq
     ra = _ddt(b, A) - DA * lap(A) + ab2 - Fc * (1.0 - A)
     rb = _ddt(b, Bq) - DB * lap(Bq) - ab2 + Fk * Bq
-    return b.done([ra, rb])
+    return b.done([ra, rb], fused_slower=True)      # pointwise around rocFFT transforms, [8, 9, 128^2]: one pass 0.284 ms, forward + adjoint 0.222
 
 
 def _gray_scott_pw():
@@ -442,7 +452,7 @@ def _gray_scott_pw():
     ab2 = A * Bq * Bq
     ra = _ddt(b, A) - DA * lA + ab2 - Fc * (1.0 - A)
     rb = _ddt(b, Bq) - DB * lB - ab2 + Fk * Bq
-    return b.done([ra, rb])
+    return b.done([ra, rb], fused_slower=True)      # pointwise around rocFFT transforms, [8, 9, 128^2]: one pass 0.284 ms, forward + adjoint 0.222
 
 
 def _active_matter_fft():
@@ -483,7 +493,7 @@ def _advection3d():
     R = _ddt(b, u) + a * _d1c4(b, u, 0, "dx") + bb * _d1c4(b, u, 1, "dy") + c * _d1c4(b, u, 2, "dz")
     # plane-marching forward and adjoint: measured 45 / 61 / 72 us against 84 / 93 / 105 us for the time-marching forward
     # (without / with residual output) and the per-frame adjoint on [2, 9, 128^3]
-    return b.done([R], **{**T3D, **Z3D, "z_first": True})
+    return b.done([R], **{**T3D, **Z3D, "z_first": True, "zcol": True, "zc_width": 4, "zc_width_bwd": 4})
 
 
 def _ape_burgers3d():
@@ -500,7 +510,7 @@ def _ape_burgers3d():
         res.append(_ddt(b, phi) + b1 * conv - a2 * lap(phi))
     # per-frame kernels (the time ring of 3-D halo tiles does not fit LDS): a near-cubic tile reads 3.4 halo floats per
     # point instead of 5.1 and leaves room for three workgroups per CU
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D})
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zcol_plain_fwd": True, "zc_width": 4, "zc_width_bwd": 2})
 
 
 def _swift_hohenberg3d():
@@ -524,7 +534,7 @@ def _heat3d():
     lap = _d2c2(b, u, 0, "dx") + _d2c2(b, u, 1, "dy") + _d2c2(b, u, 2, "dz")
     # forward and adjoint on the plane-marching kernels, residuals stored: step 0.125 ms on [2, 9, 128^3] against 0.171 ms
     # for the time-marching forward + recomputing adjoint and 0.149 ms for the fused step
-    return b.done([_ddt(b, u) - al * lap], **{**T3D, **Z3D, "z_first": True, "auto_stored": True, "fused_slower": True})      # [2, 9, 128^3]: stored 0.125 ms, one pass 0.139, recompute 0.166
+    return b.done([_ddt(b, u) - al * lap], **{**T3D, **Z3D, "z_first": True, "auto_stored": True, "fused_slower": True, "zcol": True, "zc_width": 4, "zc_width_bwd": 4})      # [2, 9, 128^3]: stored 0.125 ms, one pass 0.139, recompute 0.166
 
 
 def _tg3d():
@@ -544,7 +554,7 @@ def _tg3d():
     for ax, phi in enumerate((u, v, w)):
         conv = u * _d1c2(b, phi, 0, "dx") + v * _d1c2(b, phi, 1, "dy") + w * _d1c2(b, phi, 2, "dz")
         res.append(_ddt(b, phi) + conv + _d1c2(b, p, ax, hs[ax]) - nu * lap(phi))
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D})
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D})      # the z-column forward measured slower here (4 fields: 0.129 against 0.109 ms)
 
 
 def _ns_incom():

@@ -481,13 +481,14 @@ def check_residuals_f64(dev):
         assert float(got[eq][..., :3].abs().max()) == 0.0 and float(got[eq][..., -3:].abs().max()) == 0.0
 
 
-def check_validation_scalars(dev):
+def check_validation_scalars(dev, C=18):
     """validation_scalars (one sweep over the output) against the separate functions validate() calls
     (finetune/train_taylor_green_2d_lora_v3.py:252-275), on a plain output and on a Denormalised one: the boundary and
-    residual losses bit for bit, RMSE and VRMSE to the rounding of their fp64 sums."""
+    residual losses bit for bit, RMSE and VRMSE to the rounding of their fp64 sums.  C = 36: two LDS images of 256 points
+    would exceed a workgroup's 64 KiB, so the sweep takes the kernel without the images."""
     import pde_amd
     gen = torch.Generator().manual_seed(17)
-    B, T, H, W, C = 3, 4, 12, 20, 18
+    B, T, H, W = 3, 4, 12, 20
     on = torch.randn(B, T, H, W, C, generator=gen).to(dev)
     inp = torch.randn(B, 2, H, W, C, generator=gen).to(dev)
     tgt = torch.randn(B, T, H, W, C, generator=gen).to(dev)

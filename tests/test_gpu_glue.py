@@ -56,8 +56,9 @@ def test_residuals_f64():
     GC.check_residuals_f64(DEV)
 
 
-def test_validation_scalars_single_sweep():
-    GC.check_validation_scalars(DEV)
+@pytest.mark.parametrize("channels", [18, 36])
+def test_validation_scalars_single_sweep(channels):
+    GC.check_validation_scalars(DEV, channels)
 
 
 

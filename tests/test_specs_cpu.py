@@ -222,3 +222,24 @@ def test_scalars_out_receives_the_losses():
         mod.scalars_out = bad
         with pytest.raises(ValueError):
             mod(*fields, nu=nu)
+
+
+def test_mode_resolution_rules():
+    """'auto' / 'fused' -> kernels: the measured per-spec flags, and small problems on the stored-residual kernels"""
+    from pde_amd import functional as PF
+    from tests.spec_interp import InterpBackend
+    old = PF.set_backend(InterpBackend())
+    small, PF.SMALL_FIELD_ELEMENTS = PF.SMALL_FIELD_ELEMENTS, 2_000_000
+    try:
+        big = 16 * 16 * 256 * 256
+        assert PF.resolve_mode("fused", "tg2d", big) == "fused" and PF.resolve_mode("auto", "tg2d", big) == "recompute"
+        assert PF.resolve_mode("fused", "tg2d", 1000) == "stored" and PF.resolve_mode("auto", "tg2d", 1000) == "stored"
+        assert PF.resolve_mode("fused", "tg2d") == "fused"                       # size unknown: no rule
+        assert PF.resolve_mode("fused", "burgers1d", 1000) == "fused"            # 1-D clips are launch-bound either way
+        assert PF.resolve_mode("recompute", "tg2d", 1000) == "recompute"         # an explicit mode is kept
+        assert PF.resolve_mode("fused", "wave2d", big) == "recompute"            # fused_slower
+        assert PF.resolve_mode("fused", "gray_scott_pw", big) == "recompute"
+        assert PF.resolve_mode("auto", "heat3d", big) == "stored"                # auto_stored
+    finally:
+        PF.SMALL_FIELD_ELEMENTS = small
+        PF.set_backend(old)

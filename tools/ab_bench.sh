@@ -4,6 +4,6 @@ here=$(dirname "$0")
 for pass in 1 2; do
 for lib in "$@"; do
   echo "== $lib"
-  PDE_AMD_LIB=$lib timeout -k 10 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | python $here/ab_line.py || exit 1
+  PDE_AMD_LIB=$lib timeout -k 10 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-cases --no-traffic 2>/dev/null | python $here/ab_line.py || exit 1
 done
 done

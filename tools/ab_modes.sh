@@ -5,7 +5,7 @@ for pass in 1 2; do
 for lib in "$@"; do
 for mode in fused auto; do
   echo "== $lib $mode"
-  PDE_AMD_LIB=$lib timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --mode $mode 2>/dev/null | python $here/ab_line.py || exit 1
+  PDE_AMD_LIB=$lib timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-other-cases --no-traffic --mode $mode 2>/dev/null | python $here/ab_line.py || exit 1
 done
 done
 done

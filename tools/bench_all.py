@@ -13,6 +13,8 @@ dev = torch.device("cuda:0")
 
 
 def timeit(fn, n=15, warm=3, settle_ms=150.0):
+    if "--quick" in sys.argv:      # counter collection: a few launches, no settling
+        n, warm, settle_ms = 3, 1, 0.0
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   out=$root/gpurun_out/pmc_${tag}_$i
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $out -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-graph > $out.log 2>&1 || { echo "set $i failed"; tail -3 $out.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $out -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-other-cases --no-traffic --no-graph > $out.log 2>&1 || { echo "set $i failed"; tail -3 $out.log; exit 1; }
   i=$((i+1))
 done
 python3 - "$root" "$tag" <<'PY'

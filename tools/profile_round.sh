@@ -7,13 +7,13 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/${tag}_stats.log 2>&1 || { echo "stats run failed"; tail -5 $out/${tag}_stats.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-graph > $out/${tag}_fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-graph > $out/${tag}_write.log 2>&1 || { echo "write pass failed"; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-cases --no-traffic > $out/${tag}_stats.log 2>&1 || { echo "stats run failed"; tail -5 $out/${tag}_stats.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-other-cases --no-traffic --no-graph > $out/${tag}_fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- python3 $root/bench.py --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-other-cases --no-traffic --no-graph > $out/${tag}_write.log 2>&1 || { echo "write pass failed"; exit 1; }
 python3 - "$out" "$tag" <<'PY' | tee $out/${tag}_summary.txt
 import csv, glob, sys, collections, json
 out, tag = sys.argv[1], sys.argv[2]
-print("== rocprofv3 --kernel-trace --stats: python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline")
+print("== rocprofv3 --kernel-trace --stats: python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-cases --no-traffic")
 for f in glob.glob(f"{out}/{tag}_stats/*/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
