@@ -93,11 +93,12 @@ static inline bool aligned_vec(const float* const* p) {
     if (reinterpret_cast<uintptr_t>(p[i]) & (4 * W - 1)) return false;
   return true;
 }
-// The vector kernels address a frame with 32-bit byte offsets (bit 31 is a flag) and a sample's frames through a
-// buffer descriptor of at most 4 GiB; larger problems take the dword kernels, which use 64-bit addresses.
+// The vector kernels address a sample's frames of a field through one buffer descriptor and mark "no cell here" by the
+// lane offset 2^31, which must lie beyond the descriptor's range: 2 GiB per sample and field at most.  Larger problems
+// take the dword kernels, which use 64-bit addresses.
 static inline bool quad_addressable(const pde_amd_problem* p) {
   const long S = (long)p->n[0] * p->n[1] * p->n[2];
-  return S < (1L << 29) && (long)p->frames * S < (1L << 30);
+  return (long)p->frames * S <= (1L << 29);
 }
 static inline int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
@@ -199,13 +200,16 @@ struct Ops {
   }
 
   // z-column kernels: frames per workgroup, planes per chunk (a chunk re-reads 2 * reach planes: as long as still gives
-  // every CU a workgroup, never shorter than 8 planes), geometry; returns the number of workgroups per sample
+  // every CU a workgroup, never shorter than 8 planes), geometry; `items`: workgroups (partial sums) per sample
+  struct ZPlan { int nfw, ngroups; long items; };
   template <int LPF_, int FPW_, int T1_, int T2_>
-  static long plan_zcol(const pde_amd_problem* p, Args& a, long tr, int& nfw) {
-    const long ngroups = cdiv((int)tr, FPW_);
-    nfw = cdiv((int)tr, (int)ngroups);      // groups of equal length, up to one frame
+  static ZPlan plan_zcol(const pde_amd_problem* p, Args& a, long tr) {
+    ZPlan z;
+    z.ngroups = cdiv((int)tr, FPW_);
+    z.nfw = cdiv((int)tr, z.ngroups);      // groups of equal length, up to one frame
+    z.ngroups = cdiv((int)tr, z.nfw);
     const long yx = (long)cdiv(p->n[1], T1_) * cdiv(p->n[2], T2_);
-    const long blocks = p->batch * ngroups * yx;
+    const long blocks = (long)p->batch * z.ngroups * yx;
     int nchunk = (int)((256 + blocks - 1) / blocks);
 #ifdef PDE_AMD_DIAG_ONLY
     if (getenv("PDE_AMD_ZCHUNK")) nchunk = cdiv(p->n[0], atoi(getenv("PDE_AMD_ZCHUNK")));
@@ -215,7 +219,24 @@ struct Ops {
     if (chunk < 8) chunk = p->n[0] < 8 ? p->n[0] : 8;
     a.chunk = chunk;
     fill_geom(p, a.geo, chunk, T1_, T2_);
-    return ngroups * a.geo.nt0 * yx;
+    z.items = z.ngroups * a.geo.nt0 * yx;
+    return z;
+  }
+
+  // KF: the kernel for groups of several frames, KS: for single frames
+  template <class KF, class KS>
+  static bool launch_zcol(const pde_amd_problem* p, const Args& a, const ZPlan& z, int lpf, KF kfull, KS ksolo, size_t lds, hipStream_t stream) {
+    const void* fn = z.nfw == 1 ? reinterpret_cast<const void*>(ksolo) : reinterpret_cast<const void*>(kfull);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    ZColLaunch zl;
+    zl.nfw = z.nfw; zl.ngroups = z.ngroups;
+    const unsigned grid = (unsigned)((long)p->batch * z.items);
+    if (z.nfw == 1) hipLaunchKernelGGL(ksolo, dim3(grid), dim3(lpf), lds, stream, a, zl);
+    else hipLaunchKernelGGL(kfull, dim3(grid), dim3(lpf * z.nfw), lds, stream, a, zl);
+    return true;
   }
 
   // -1: too many workgroups; -2: more partial sums than `cap`; -3: the kernel's LDS could not be granted
@@ -223,25 +244,19 @@ struct Ops {
   static long launch_zcol_forward(const pde_amd_problem* p, Args& a, long tr, long cap, hipStream_t stream) {
     if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
       using C = ZColCfg<P, P::ZCW>;
-      int nfw;
-      const long items = plan_zcol<C::LPF, C::FPWF, C::T1, C::T2>(p, a, tr, nfw);
-      if (p->batch * items >= (1L << 31)) return -1;
-      if (items > cap) return -2;
-      const size_t lds = C::fwd_lds(nfw);
-      auto kern = fwd_zcol_kernel<P, P::ZCW, WRITE_R>;
-      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return -3;
-      }
-      hipLaunchKernelGGL(kern, dim3((unsigned)(p->batch * items)), dim3(C::LPF * nfw), lds, stream, a, nfw);
-      return items;
+      const ZPlan z = plan_zcol<C::LPF, C::FPWF, C::T1, C::T2>(p, a, tr);
+      if (p->batch * z.items >= (1L << 31)) return -1;
+      if (z.items > cap) return -2;
+      if (!launch_zcol(p, a, z, C::LPF, fwd_zcol_kernel<P, P::ZCW, WRITE_R, false>, fwd_zcol_kernel<P, P::ZCW, WRITE_R, true>,
+                       C::fwd_lds(z.nfw), stream)) return -3;
+      return z.items;
     }
     return -3;
   }
 
   template <int W = P::ZCW>
   static bool zcol_usable(const pde_amd_problem* p, const float* const* fields) {
-    return p->n[2] % W == 0 && aligned_vec<P::NF, W>(fields) && (long)p->n[1] * p->n[2] < (1L << 30);
+    return p->n[2] % W == 0 && aligned_vec<P::NF, W>(fields) && quad_addressable(p);
   }
 
   static size_t ws_bytes(const pde_amd_problem* p) {
@@ -537,20 +552,11 @@ struct Ops {
       if constexpr (ZColCfg<P, P::ZCWB>::BWD_OK) {
         if (zcol_usable<P::ZCWB>(p, fields) && aligned_vec<P::NF, P::ZCWB>(grads) && aligned_vec<P::NE, P::ZCWB>(resid_in)) {
           using C = ZColCfg<P, P::ZCWB>;
-          int nfw;
-          const long items = plan_zcol<C::LPF, C::FPWB, C::T1, C::T2>(p, a, tr, nfw);
-          if (p->batch * items >= (1L << 31)) return PDE_AMD_ESHAPE;
-          const size_t lds = C::bwd_lds(nfw);
-          const bool multi = tr > nfw;
-          auto kern = multi ? bwd_stored_zcol_kernel<P, P::ZCWB, true> : bwd_stored_zcol_kernel<P, P::ZCWB, false>;
-          bool ok = true;
-          if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            ok = false;
-          }
-          if (ok) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p->batch * items)), dim3(C::LPF * nfw), lds, stream, a, nfw);
-            note_kernel("bwd_stored_zcol_kernel", P::NAME, P::ZCWB == 2 ? (multi ? ", 2, true" : ", 2, false") : (multi ? ", 4, true" : ", 4, false"));
+          const ZPlan z = plan_zcol<C::LPF, C::FPWB, C::T1, C::T2>(p, a, tr);
+          if (p->batch * z.items >= (1L << 31)) return PDE_AMD_ESHAPE;
+          if (launch_zcol(p, a, z, C::LPF, bwd_stored_zcol_kernel<P, P::ZCWB, false>, bwd_stored_zcol_kernel<P, P::ZCWB, true>,
+                          C::bwd_lds(z.nfw), stream)) {
+            note_kernel("bwd_stored_zcol_kernel", P::NAME, P::ZCWB == 2 ? (z.nfw == 1 ? ", 2, true" : ", 2, false") : (z.nfw == 1 ? ", 4, true" : ", 4, false"));
             launched = true;
           }
         }
@@ -638,7 +644,18 @@ struct Ops {
 };
 
 #ifdef PDE_AMD_DIAG_ONLY      // diagnostic builds (-DPDE_AMD_DIAG_ONLY=Pde_tg2d): every slot runs that PDE's kernels; compiles in seconds
+#ifdef PDE_AMD_DIAG_ZCW       // ... with other lane widths of the z-column kernels (-DPDE_AMD_DIAG_ZCW=2 -DPDE_AMD_DIAG_ZCWB=2)
+#ifndef PDE_AMD_DIAG_ZCT1
+#define PDE_AMD_DIAG_ZCT1 PDE_AMD_DIAG_ONLY::ZCT1
+#define PDE_AMD_DIAG_ZCT2 PDE_AMD_DIAG_ONLY::ZCT2
+#endif
+struct DiagPde : PDE_AMD_DIAG_ONLY {
+  static constexpr int ZCW = PDE_AMD_DIAG_ZCW, ZCWB = PDE_AMD_DIAG_ZCWB, ZCT1 = PDE_AMD_DIAG_ZCT1, ZCT2 = PDE_AMD_DIAG_ZCT2;
+};
+#define PDE_AMD_VT(P) Ops<DiagPde>::vtable(),
+#else
 #define PDE_AMD_VT(P) Ops<PDE_AMD_DIAG_ONLY>::vtable(),
+#endif
 #else
 #define PDE_AMD_VT(P) Ops<P>::vtable(),
 #endif
@@ -775,12 +792,16 @@ const char* pde_amd_last_adjoint_kernel(void) { return t_kernel; }
 #ifdef PDE_AMD_DIAG_ONLY
 // diagnostic builds only: workgroups per CU the runtime grants the z-column kernels of the build's PDE
 void pde_amd_diag_zcol_occupancy(void) {
+#ifdef PDE_AMD_DIAG_ZCW
+  using P = DiagPde;
+#else
   using P = PDE_AMD_DIAG_ONLY;
+#endif
   if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
     using C = ZColCfg<P, P::ZCW>;
     for (int nfw = 1; nfw <= C::FPWF; ++nfw) {
       int n = -1;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fwd_zcol_kernel<P, P::ZCW, true>, C::LPF * nfw, C::fwd_lds(nfw));
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fwd_zcol_kernel<P, P::ZCW, true, false>, C::LPF * nfw, C::fwd_lds(nfw));
       printf("fwd_zcol nfw=%d threads=%d lds=%zu -> %d workgroups per CU (%s)\n", nfw, C::LPF * nfw, C::fwd_lds(nfw), n, hipGetErrorString(e));
     }
   }

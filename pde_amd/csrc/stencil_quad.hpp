@@ -64,7 +64,15 @@ template <> struct BufIO<2> {
   static __device__ __forceinline__ void store_nt(fv v, __amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uv, v), r, lane, frame, 2);
   }
+  static __device__ __forceinline__ void store(fv v, __amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uv, v), r, lane, frame, 0);
+  }
 };
+// The 16-byte stores carry the frame offset in the lane offset, never in the scalar offset register: a store of more
+// than 8 bytes per lane reads its data registers over several cycles, and a vector instruction that overwrites them
+// right behind it corrupts what is stored.  The compiler spaces the two apart on its own only when the store has no
+// scalar offset register; with one it assumes the hardware interlocks, which gfx950 was measured not to do once two
+// waves share a SIMD (first data register of the last lanes of each 16 written with the next value).
 template <> struct BufIO<4> {
   typedef unsigned uv __attribute__((ext_vector_type(4)));
   typedef VecOf<4>::type fv;
@@ -72,7 +80,10 @@ template <> struct BufIO<4> {
     return __builtin_bit_cast(fv, __builtin_amdgcn_raw_buffer_load_b128(r, lane, frame, 0));
   }
   static __device__ __forceinline__ void store_nt(fv v, __amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uv, v), r, lane, frame, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uv, v), r, lane + frame, 0, 2);
+  }
+  static __device__ __forceinline__ void store(fv v, __amdgpu_buffer_rsrc_t r, unsigned lane, unsigned frame) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uv, v), r, lane + frame, 0, 0);
   }
 };
 

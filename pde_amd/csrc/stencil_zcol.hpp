@@ -5,10 +5,15 @@
 // frame is fetched up to three times.  Here a workgroup marches a (y, x) tile through a chunk of z planes for a whole
 // group of residual frames at once: a set of waves per frame, all at the same plane, one barrier per plane.
 //   * the time taps of a frame are the plane images of its neighbours in LDS (the group's two outer frames, which have
-//     no waves of their own, are staged by the waves of the first and last frame);
+//     no waves of their own, are staged by the waves of the group's first and last frame);
 //   * the taps along z come out of the lane's own registers (a column of 2 * reach + 1 planes of its cell), so LDS holds
 //     ONE plane per frame and field (twice: the image of plane k + 1 is written while plane k is read) instead of a ring;
 //   * every plane of every frame is fetched once per (y, x) tile.
+// The loop body holds no vector-memory instruction under a branch: lanes that have nothing to load or store pass an
+// offset beyond the buffer's size (the load returns zeros, the store is dropped).  The memory counter of a wave is in
+// order, and where two paths with different numbers of loads and stores meet, the compiler has to wait for the longer
+// path's count: the stores of one step would then have to complete before the next step may use what it loaded.  With
+// one path, every wait names exactly the loads it needs and the stores drain behind the next step's arithmetic.
 // Requirements (ZColCfg): a 3-D PDE, periodic on every axis, without auxiliary fields, whose z taps are pure (no (y, x)
 // offset on a tap with a z offset), whose time taps are pointwise one frame back and ahead, and (adjoint) whose field
 // reads are at the output point.  Everything else keeps the kernels of stencil_zmarch.hpp / stencil_quad.hpp.
@@ -17,37 +22,36 @@
 
 namespace pde_amd {
 
-template <class P, int W>
-struct ZColCfg {
-  static constexpr bool ON = P::ND == 3 && P::ZCOL != 0 && P::ZPURE != 0 && P::NA == 0 && P::TLO == 1 && P::THI == 1 &&
-                             (P::RT0 | P::RT1 | P::RT2) == 0 && P::PER0 && P::PER1 && P::PER2;
-  static constexpr int T1 = ON ? P::ZCT1 : 8, T2 = ON ? P::ZCT2 : 32;
-  static constexpr int QR = T2 / W;              // cells (W points) per tile row
-  static constexpr int LPF = T1 * QR;            // lanes per frame: one cell each
 #ifndef PDE_AMD_ZCOL_MAXTF
 #define PDE_AMD_ZCOL_MAXTF 512
 #endif
 #ifndef PDE_AMD_ZCOL_MAXTB
 #define PDE_AMD_ZCOL_MAXTB 512
 #endif
-  // lanes per workgroup at most: it bounds the registers a lane may use (512 lanes: 256, 768: 168, 1024: 128)
-  static constexpr int MAXTF = PDE_AMD_ZCOL_MAXTF, MAXTB = PDE_AMD_ZCOL_MAXTB;
-  static constexpr int FPWF = MAXTF / LPF, FPWB = MAXTB / LPF;      // residual frames per workgroup at most
 #ifndef PDE_AMD_ZCOL_WPSF
 #define PDE_AMD_ZCOL_WPSF 1
 #endif
 #ifndef PDE_AMD_ZCOL_WPSB
 #define PDE_AMD_ZCOL_WPSB 1
 #endif
+
+template <class P, int W>
+struct ZColCfg {
+  static constexpr bool ON = P::ND == 3 && P::ZCOL != 0 && P::ZPURE != 0 && P::NA == 0 && P::TLO == 1 && P::THI == 1 &&
+                             (P::RT0 | P::RT1 | P::RT2) == 0 && P::PER0 && P::PER1 && P::PER2 && (W == 2 || W == 4);
+  static constexpr int T1 = ON ? P::ZCT1 : 8, T2 = ON ? P::ZCT2 : 32;
+  static constexpr int QR = T2 / W;              // cells (W points) per tile row
+  static constexpr int LPF = T1 * QR;            // lanes per frame: one cell each
+  // lanes per workgroup at most: it bounds the registers a lane may use (512 lanes: 256, 768: 168, 1024: 128)
+  static constexpr int MAXTF = PDE_AMD_ZCOL_MAXTF, MAXTB = PDE_AMD_ZCOL_MAXTB;
+  static constexpr int FPWF = MAXTF / LPF, FPWB = MAXTB / LPF;      // residual frames per workgroup at most
   static constexpr int WPSF = PDE_AMD_ZCOL_WPSF, WPSB = PDE_AMD_ZCOL_WPSB;      // waves per SIMD to compile for
   using TP = Tile<1, T1, T2, 0, P::RH1, padw<W>(P::RH2)>;      // plane image of a field: the residual's (y, x) halo
   using TG = Tile<1, T1, T2, 0, P::GH1, padw<W>(P::GH2)>;      // plane image of a scaled residual: the adjoint's halo
   static constexpr bool SHAPE_OK = T2 % W == 0 && LPF % 64 == 0 && LPF <= 512;
   static constexpr bool FWD_OK = ON && SHAPE_OK;
 #ifdef PDE_AMD_ZCOL_NOBWD      // diagnostic builds: the adjoint keeps the other kernels
-  static constexpr bool BWD_OK = false && (P::GT0 | P::GT1 | P::GT2) == 0 && P::GTLO == 1 && P::GTHI == 1 &&
-                                 P::ATLO == 0 && P::ATHI == 0 && (P::AH0 | P::AH1 | P::AH2) == 0 &&
-                                 (P::AT0 | P::AT1 | P::AT2) == 0 && P::TIME_AF == 0;
+  static constexpr bool BWD_OK = false;
 #else
   static constexpr bool BWD_OK = ON && SHAPE_OK && (P::GT0 | P::GT1 | P::GT2) == 0 && P::GTLO == 1 && P::GTHI == 1 &&
                                  P::ATLO == 0 && P::ATHI == 0 && (P::AH0 | P::AH1 | P::AH2) == 0 &&
@@ -59,6 +63,10 @@ struct ZColCfg {
   static size_t bwd_lds(int nfw) { return RED_BYTES + 2ul * (nfw + 2) * P::NE * TG::SIZE * sizeof(float); }
 };
 
+// A lane offset no buffer of these kernels reaches (they are launched for clips of at most 2 GiB per field): loads through
+// it return zeros, stores through it are dropped.  Far from 2^32, so that offset + access width cannot wrap into range.
+constexpr unsigned ZC_NOWHERE = 0x80000000u;
+
 // The cells of a plane image that are not the tile's own: rows above and below (whole image rows), then the side cells
 // of the tile's rows.  Dealt to the lanes of a frame; offsets computed once per workgroup, periodic wrap applied.
 template <class TL, int W, int LPF>
@@ -66,7 +74,7 @@ struct HaloCells {
   static constexpr int QD = TL::D2 / W, HQ = TL::H2 / W, QT = TL::T2 / W;
   static constexpr int NH = 2 * TL::H1 * QD + TL::T1 * 2 * HQ;
   static constexpr int EPT = NH > 0 ? (NH + LPF - 1) / LPF : 1;
-  unsigned goff[EPT];      // element offset inside a plane
+  unsigned goff[EPT];      // byte offset inside a plane; ZC_NOWHERE: this lane has no cell j
   int lds[EPT];            // float offset inside the plane image; < 0: this lane has no cell j
   __device__ __forceinline__ void init(int lid, int o1, int o2, const Geom& g) {
 #pragma unroll
@@ -80,7 +88,7 @@ struct HaloCells {
       const int c1 = wrap_coord<true>(o1 + l1 - TL::H1, g.N1, ok);
       const int c2 = wrap_quad<true, W>(o2 + W * lq - TL::H2, g.N2, ok);
       const bool have = NH > 0 && i < NH;
-      goff[j] = have ? (unsigned)(c1 * g.N2 + c2) : 0u;
+      goff[j] = have ? 4u * (unsigned)(c1 * g.N2 + c2) : ZC_NOWHERE;
       lds[j] = have ? l1 * TL::S1 + W * lq : -1;
     }
   }
@@ -116,6 +124,13 @@ struct ZColItem {
   }
 };
 
+// What a launch of the z-column kernels covers besides Args: the clip's residual frames in `ngroups` groups of `nfw`
+// frames each; the last group may be shorter, and the waves of its missing frames run along with every lane offset
+// "nowhere" (they load zeros, store nothing, write no image), so that the loop stays free of branches around memory.
+struct ZColLaunch {
+  int nfw, ngroups;
+};
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -141,51 +156,75 @@ struct ZColResAcc : SiteBase<P> {
   __device__ __forceinline__ float G(int, int, int, int, int) const { return 0.0f; }
 };
 
-// launched with LPF * nfw threads and ZColCfg::fwd_lds(nfw) bytes of dynamic LDS
-template <class P, int W, bool WRITE_R>
-__global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void fwd_zcol_kernel(const Args a, const int nfw) {
+// launched with LPF * nfw threads and ZColCfg::fwd_lds(nfw) bytes of dynamic LDS.  SOLO: one frame per workgroup, whose
+// waves stage both outer frames; otherwise the waves of the group's first frame stage the frame before it and those of
+// its last frame the one after.
+template <class P, int W, bool WRITE_R, bool SOLO>
+__global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void fwd_zcol_kernel(const Args a, const ZColLaunch zl) {
   using C = ZColCfg<P, W>;
   using TP = typename C::TP;
   using fv = typename VecOf<W>::type;
   using HC = HaloCells<TP, W, C::LPF>;
   constexpr int LPF = C::LPF, RH0 = P::RH0, NZ = 2 * RH0 + 1, NF = P::NF, NE = P::NE, QR = C::QR, EPT = HC::EPT;
+  constexpr int NED = SOLO ? 2 : 1;      // outer frames a wave may have to stage
   static_assert(C::FWD_OK, "PDE not eligible for the z-column forward");
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   double* s_red = reinterpret_cast<double*>(s_raw);
   float* s_img = reinterpret_cast<float*>(s_raw + C::RED_BYTES);
 
   const Geom& g = a.geo;      // nt1, nt2: (y, x) tiles; nt0: chunks of planes; a.chunk: planes per chunk
+  const int nfw = zl.nfw;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int ngroups = (g.TR + nfw - 1) / nfw;
-  const ZColItem it(w, g, ngroups);
-  const int fw = threadIdx.x / LPF, lid = threadIdx.x % LPF;      // fw is wave-uniform: LPF is a multiple of 64
-  const int nlive = min(nfw, g.TR - it.grp * nfw);                // frames of this group (the last group may be short)
+  const ZColItem it(w, g, zl.ngroups);
+  // fw is wave-uniform (LPF is a multiple of 64); said so explicitly, everything derived from it (frame offsets, image
+  // slots) stays in scalar registers and the buffer instructions take it as their scalar offset
+  const int fw = __builtin_amdgcn_readfirstlane((int)threadIdx.x / LPF), lid = threadIdx.x % LPF;
+  const int nlive = min(nfw, g.TR - it.grp * nfw);      // frames of this group
   const bool live = fw < nlive;
   const int tr = it.grp * nfw + min(fw, nlive - 1), t = tr + 1;
   const int o2 = (it.tile % g.nt2) * TP::T2, o1 = (it.tile / g.nt2) * TP::T1;
   const int za = it.zc * a.chunk, zb = min(za + a.chunk, g.N0);
-  const int plane = g.N1 * g.N2;
+  const unsigned plane4 = 4u * (unsigned)(g.N1 * g.N2), frame4 = 4u * (unsigned)g.S;
   const int bufsz = (nfw + 2) * NF * TP::SIZE;
-  const bool first = live && fw == 0, last = live && fw == nlive - 1;      // these waves also stage the group's outer frames
 
   // own cell
   const int row = lid / QR, l2 = W * (lid % QR);
   const int pi1 = o1 + row, pi2 = o2 + l2;
   const bool inside = pi1 < g.N1 && pi2 < g.N2;
   const bool rowok = inside && pi1 >= g.lo1 && pi1 < g.N1 - g.hi1;
-  unsigned ooff;      // element offset of the cell inside a plane; cells past the grid's end hold the periodic image
+  unsigned ooff;      // byte offset of the cell inside a plane; cells past the grid's end hold the periodic image
   {
     bool ok = true;
     const int c1 = wrap_coord<true>(pi1, g.N1, ok), c2 = wrap_quad<true, W>(pi2, g.N2, ok);
-    ooff = (unsigned)(c1 * g.N2 + c2);
+    ooff = live ? 4u * (unsigned)(c1 * g.N2 + c2) : ZC_NOWHERE;
   }
+  const unsigned soff = live && inside ? 4u * (unsigned)(pi1 * g.N2 + pi2) : ZC_NOWHERE;      // where the cell's results go
   const int olds = TP::at(0, row, l2);
   HC hc;
   hc.init(lid, o1, o2, g);
-
-  const float* fb[NF];
+  if (!live) {
 #pragma unroll
-  for (int f = 0; f < NF; ++f) fb[f] = a.f[f] + ((long)it.b * g.T + t) * g.S;
+    for (int j = 0; j < EPT; ++j) hc.goff[j] = ZC_NOWHERE;
+  }
+
+  __amdgpu_buffer_rsrc_t fbuf[NF], rbuf[NE];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) fbuf[f] = buffer_of(a.f[f] + (long)it.b * g.T * g.S, 4u * (unsigned)(g.T * g.S));
+#pragma unroll
+  for (int e = 0; e < NE; ++e) rbuf[e] = buffer_of(WRITE_R ? a.rout[e] + (long)it.b * g.TR * g.S : a.f[0], WRITE_R ? 4u * (unsigned)(g.TR * g.S) : 0u);
+  const unsigned fr = (unsigned)t * frame4;      // this frame inside the sample's fields
+  // the outer frame(s) this wave stages: byte offset of the frame, image slot, lane offset (nowhere: none)
+  unsigned efr[NED], eoff[NED];
+  int eslot[NED];
+  if (SOLO) {
+    efr[0] = fr - frame4; eslot[0] = 0; eoff[0] = ooff;
+    efr[NED - 1] = fr + frame4; eslot[NED - 1] = 2; eoff[NED - 1] = ooff;
+  } else {
+    const bool lo = fw == 0, hi = fw == nlive - 1;
+    efr[0] = lo ? fr - frame4 : fr + frame4;
+    eslot[0] = lo ? 0 : nlive + 1;
+    eoff[0] = lo || hi ? ooff : ZC_NOWHERE;
+  }
 
   ZColResAcc<P, TP, W> acc;
   acc.template set_uniforms<true>(a.c, a.sp, it.b);
@@ -193,107 +232,83 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
   acc.i1 = pi1;
   float wk[NE];
 #pragma unroll
-  for (int k = 0; k < NE; ++k) wk[k] = ldc(a.wt, k * g.TR + tr);
+  for (int k = 0; k < NE; ++k) wk[k] = live ? ldc(a.wt, k * g.TR + tr) : 0.0f;
   double sum[NE];
 #pragma unroll
   for (int k = 0; k < NE; ++k) sum[k] = 0.0;
 
-  // the column of the first plane, its halo cells and the outer frames' cells: all in flight together
-  fv hal[NF][EPT], elo[NF], ehi[NF], nxt[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    elo[f] = ehi[f] = nxt[f] = vec_zero<W>();
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) hal[f][j] = vec_zero<W>();
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) acc.col[f][i] = vec_zero<W>();
-  }
+  // the column of the first plane, its halo cells and the outer frames' cells, then the first image
+  fv hal[NF][EPT], edg[NED][NF], nxt[NF];
   PlaneCursor<true> cur;      // the plane that enters the column next
-  cur.init(za + RH0 + 1, g.N0, plane);
-  if (live) {
+  cur.init(za + RH0 + 1, g.N0, 1);
+  {
     bool on;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
-      const int pz = z_plane<true>(za - RH0 + i, g.N0, on);
+      const unsigned pz = (unsigned)z_plane<true>(za - RH0 + i, g.N0, on) * plane4;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) acc.col[f][i] = *reinterpret_cast<const fv*>(fb[f] + (long)pz * plane + ooff);
+      for (int f = 0; f < NF; ++f) acc.col[f][i] = BufIO<W>::load(fbuf[f], ooff, fr + pz);
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) hal[f][j] = *reinterpret_cast<const fv*>(fb[f] + (long)za * plane + hc.goff[j]);
-    }
-    if (first) {
+      for (int j = 0; j < EPT; ++j) hal[f][j] = BufIO<W>::load(fbuf[f], hc.goff[j], fr + (unsigned)za * plane4);
 #pragma unroll
-      for (int f = 0; f < NF; ++f) elo[f] = *reinterpret_cast<const fv*>(fb[f] - g.S + (long)za * plane + ooff);
-    }
-    if (last) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) ehi[f] = *reinterpret_cast<const fv*>(fb[f] + g.S + (long)za * plane + ooff);
+      for (int s = 0; s < NED; ++s) edg[s][f] = BufIO<W>::load(fbuf[f], eoff[s], efr[s] + (unsigned)za * plane4);
     }
   }
-  long ko = (long)za * plane;          // element offset of plane k inside a frame
-  const long rframe = ((long)it.b * g.TR + tr) * g.S;
-
-  // The residuals of plane k are stored at the top of step k + 1, ahead of that step's loads: the memory counter is in
-  // order, so stores issued after a step's loads would have to complete before the next step may use what it loaded.
-  fv rst[NE];
+  auto write_image = [&](float* img) __attribute__((always_inline)) {
+    if (!live) return;
+    float* mine = img + (fw + 1) * NF * TP::SIZE;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) rst[e] = vec_zero<W>();
-  const long rown = rframe + (long)pi1 * g.N2 + pi2;
+    for (int f = 0; f < NF; ++f) {
+      *reinterpret_cast<fv*>(mine + f * TP::SIZE + olds) = acc.col[f][RH0];
+#pragma unroll
+      for (int j = 0; j < EPT; ++j)
+        if (hc.lds[j] >= 0) *reinterpret_cast<fv*>(mine + f * TP::SIZE + hc.lds[j]) = hal[f][j];
+#pragma unroll
+      for (int s = 0; s < NED; ++s)
+        if (eoff[s] != ZC_NOWHERE) *reinterpret_cast<fv*>(img + (eslot[s] * NF + f) * TP::SIZE + olds) = edg[s][f];
+    }
+  };
+  write_image(s_img);
+  unsigned ko = (unsigned)za * plane4;          // byte offset of plane k inside a frame
+  const unsigned rfr = (unsigned)tr * frame4;   // this residual frame inside the sample's residuals
 
   for (int k = za; k < zb; ++k) {
     float* img = s_img + ((k - za) & 1) * bufsz;
-    float* mine = img + (fw + 1) * NF * TP::SIZE;
-    if (live) {
+    __syncthreads();      // the image of plane k is complete, and nobody reads the other buffer any more
+    // plane k + 1 (the last step fetches its own plane again, and what it writes below is never read): the column's
+    // next entry, the halo cells, the outer frames; in flight during the step
+    const unsigned kn = k + 1 < zb ? ko + plane4 : ko;
+#ifndef PDE_AMD_ZC_NOLOAD
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        *reinterpret_cast<fv*>(mine + f * TP::SIZE + olds) = acc.col[f][RH0];
+    for (int f = 0; f < NF; ++f) {
+      nxt[f] = BufIO<W>::load(fbuf[f], ooff, fr + (unsigned)cur.p * plane4);
 #pragma unroll
-        for (int j = 0; j < EPT; ++j)
-          if (hc.lds[j] >= 0) *reinterpret_cast<fv*>(mine + f * TP::SIZE + hc.lds[j]) = hal[f][j];
-      }
-      if (first) {
+      for (int j = 0; j < EPT; ++j) hal[f][j] = BufIO<W>::load(fbuf[f], hc.goff[j], fr + kn);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) *reinterpret_cast<fv*>(img + f * TP::SIZE + olds) = elo[f];
-      }
-      if (last) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) *reinterpret_cast<fv*>(mine + (NF + f) * TP::SIZE + olds) = ehi[f];
-      }
-      if (WRITE_R && inside && k > za) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) *reinterpret_cast<fv*>(a.rout[e] + rown + ko - plane) = rst[e];
-      }
+      for (int s = 0; s < NED; ++s) edg[s][f] = BufIO<W>::load(fbuf[f], eoff[s], efr[s] + kn);
     }
-    __syncthreads();
-    const bool more = k + 1 < zb;
-    if (live && more) {      // plane k + 1: the column's next entry, the halo cells, the outer frames; in flight during the step
+#else      // ablation (wrong results): no global loads inside the loop
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        nxt[f] = *reinterpret_cast<const fv*>(fb[f] + cur.off + ooff);
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) hal[f][j] = *reinterpret_cast<const fv*>(fb[f] + ko + plane + hc.goff[j]);
-      }
-      if (first) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) elo[f] = *reinterpret_cast<const fv*>(fb[f] - g.S + ko + plane + ooff);
-      }
-      if (last) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) ehi[f] = *reinterpret_cast<const fv*>(fb[f] + g.S + ko + plane + ooff);
-      }
-    }
-    cur.advance(g.N0, plane);
-    if (live) {
+    for (int f = 0; f < NF; ++f) nxt[f] = acc.col[f][0];
+#endif
+    cur.advance(g.N0, 1);
+    {
       acc.i0 = k;
-      acc.site = mine + olds;
+      acc.site = img + (fw + 1) * NF * TP::SIZE + olds;
       const bool zok = k >= g.lo0 && k < g.N0 - g.hi0;
       float Rq[W][NE];
 #pragma unroll
       for (int px = 0; px < W; ++px) {
         acc.px = px; acc.i2 = pi2 + px;
+#ifdef PDE_AMD_ZC_NOCOMP      // ablation (wrong results): a few taps instead of the residual
+#pragma unroll
+        for (int e = 0; e < NE; ++e) Rq[px][e] = acc.F(e % NF, 0, -RH0, 0, 0) + acc.F(e % NF, 0, RH0, 0, 0) + acc.F(e % NF, 0, 0, 1, 0) + acc.F(e % NF, 1, 0, 0, 0);
+#else
         P::residual(acc, Rq[px]);
+#endif
         const bool ok = zok && rowok && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
 #pragma unroll
         for (int e = 0; e < NE; ++e) Rq[px][e] = ok ? Rq[px][e] : 0.0f;
@@ -307,9 +322,12 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
       }
       if (WRITE_R) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e)
+        for (int e = 0; e < NE; ++e) {
+          fv r;
 #pragma unroll
-          for (int px = 0; px < W; ++px) rst[e][px] = Rq[px][e];
+          for (int px = 0; px < W; ++px) r[px] = Rq[px][e];
+          BufIO<W>::store(r, rbuf[e], soff, rfr + ko);
+        }
       }
     }
 #pragma unroll
@@ -318,15 +336,8 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
       for (int i = 0; i + 1 < NZ; ++i) acc.col[f][i] = acc.col[f][i + 1];
       acc.col[f][NZ - 1] = nxt[f];
     }
-    ko += plane;
-  }
-  if (WRITE_R && live && inside && zb > za) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) *reinterpret_cast<fv*>(a.rout[e] + rown + ko - plane) = rst[e];
-  }
-  if (!live) {
-#pragma unroll
-    for (int k = 0; k < NE; ++k) sum[k] = 0.0;
+    ko += plane4;
+    write_image(s_img + ((k + 1 - za) & 1) * bufsz);      // plane k + 1 into the buffer nobody reads during this step
   }
   __syncthreads();
   block_sum_store_rt<NE>(sum, s_red, a.partial + (long)w * NE);
@@ -372,35 +383,34 @@ struct ZColEdgeAcc : SiteBase<P> {
 };
 
 // launched with LPF * nfw threads and ZColCfg::bwd_lds(nfw) bytes of dynamic LDS; waves <-> residual frames, the waves of
-// residual frame tr write the gradient of frame tr + 1 (and of the clip's first / last frame where tr is the first / last)
-// MULTI: the clip is split into several frame groups (a group then also stages the scaled residuals of the residual
-// frames next to it, which belong to other groups); the usual clips are one group and spare those registers
-template <class P, int W, bool MULTI>
-__global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void bwd_stored_zcol_kernel(const Args a, const int nfw) {
+// residual frame tr write the gradient of frame tr + 1 (and of the clip's first / last frame where tr is the first / last).
+// SOLO as in the forward kernel; the outer slots hold the scaled residuals of the residual frames next to the group, which
+// belong to other groups (zeros where the clip ends).
+template <class P, int W, bool SOLO>
+__global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void bwd_stored_zcol_kernel(const Args a, const ZColLaunch zl) {
   using C = ZColCfg<P, W>;
   using TG = typename C::TG;
   using fv = typename VecOf<W>::type;
   using HC = HaloCells<TG, W, C::LPF>;
   constexpr int LPF = C::LPF, GH0 = P::GH0, NZ = 2 * GH0 + 1, NF = P::NF, NE = P::NE, QR = C::QR, EPT = HC::EPT;
+  constexpr int NED = SOLO ? 2 : 1;
   constexpr bool AF = P::ANY_AF != 0;
   static_assert(C::BWD_OK, "PDE not eligible for the z-column stored-residual adjoint");
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   float* s_img = reinterpret_cast<float*>(s_raw + C::RED_BYTES);
 
   const Geom& g = a.geo;
+  const int nfw = zl.nfw;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int ngroups = (g.TR + nfw - 1) / nfw;
-  const ZColItem it(w, g, ngroups);
-  const int fw = threadIdx.x / LPF, lid = threadIdx.x % LPF;
+  const ZColItem it(w, g, zl.ngroups);
+  const int fw = __builtin_amdgcn_readfirstlane((int)threadIdx.x / LPF), lid = threadIdx.x % LPF;
   const int nlive = min(nfw, g.TR - it.grp * nfw);
   const bool live = fw < nlive;
   const int tr = it.grp * nfw + min(fw, nlive - 1), t = tr + 1;
   const int o2 = (it.tile % g.nt2) * TG::T2, o1 = (it.tile / g.nt2) * TG::T1;
   const int za = it.zc * a.chunk, zb = min(za + a.chunk, g.N0);
-  const int plane = g.N1 * g.N2;
+  const unsigned plane4 = 4u * (unsigned)(g.N1 * g.N2), frame4 = 4u * (unsigned)g.S;
   const int bufsz = (nfw + 2) * NE * TG::SIZE;
-  const bool first = live && fw == 0, last = live && fw == nlive - 1;
-  const bool has_lo = MULTI && first && tr > 0, has_hi = MULTI && last && tr + 1 < g.TR;      // a residual frame of another group next to this one
 
   const int row = lid / QR, l2 = W * (lid % QR);
   const int pi1 = o1 + row, pi2 = o2 + l2;
@@ -409,28 +419,57 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
   {
     bool ok = true;
     const int c1 = wrap_coord<true>(pi1, g.N1, ok), c2 = wrap_quad<true, W>(pi2, g.N2, ok);
-    ooff = (unsigned)(c1 * g.N2 + c2);
+    ooff = live ? 4u * (unsigned)(c1 * g.N2 + c2) : ZC_NOWHERE;
   }
+  const unsigned soff = live && inside ? 4u * (unsigned)(pi1 * g.N2 + pi2) : ZC_NOWHERE;
+  // the clip's first / last frame get their gradient from the waves of the first / last residual frame
+  const unsigned soff_first = tr == 0 ? soff : ZC_NOWHERE, soff_last = tr == g.TR - 1 ? soff : ZC_NOWHERE;
   const int olds = TG::at(0, row, l2);
   HC hc;
   hc.init(lid, o1, o2, g);
+  if (!live) {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) hc.goff[j] = ZC_NOWHERE;
+  }
 
-  const float* rp[NE];
+  __amdgpu_buffer_rsrc_t rbuf[NE], fbuf[NF], gbuf[NF];
 #pragma unroll
-  for (int k = 0; k < NE; ++k) rp[k] = a.r[k] + ((long)it.b * g.TR + tr) * g.S;
-  const float* fb[NF];
-  float* gb[NF];
+  for (int e = 0; e < NE; ++e) rbuf[e] = buffer_of(a.r[e] + (long)it.b * g.TR * g.S, 4u * (unsigned)(g.TR * g.S));
 #pragma unroll
-  for (int f = 0; f < NF; ++f) { fb[f] = a.f[f] + ((long)it.b * g.T + t) * g.S; gb[f] = a.g[f] + ((long)it.b * g.T + t) * g.S; }
+  for (int f = 0; f < NF; ++f) {
+    fbuf[f] = buffer_of(a.f[f] + (long)it.b * g.T * g.S, 4u * (unsigned)(g.T * g.S));
+    gbuf[f] = buffer_of(a.g[f] + (long)it.b * g.T * g.S, 4u * (unsigned)(g.T * g.S));
+  }
+  const unsigned rfr = (unsigned)tr * frame4, fr = (unsigned)t * frame4;
 
   float up[NE];
   upstream_of<P>(a, it.b, up);
-  float cf[NE], cflo[NE], cfhi[NE];      // coefficients of this residual frame and of the group's outer residual frames
+  float cf[NE];      // coefficient of this residual frame
 #pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    cf[k] = up[k] * ldc(a.wt, k * g.TR + tr);
-    cflo[k] = up[k] * ldc(a.wt, k * g.TR + max(tr - 1, 0));
-    cfhi[k] = up[k] * ldc(a.wt, k * g.TR + min(tr + 1, g.TR - 1));
+  for (int k = 0; k < NE; ++k) cf[k] = up[k] * ldc(a.wt, k * g.TR + tr);
+  // the outer residual frame(s) this wave stages: byte offset, image slot, lane offset (nowhere: zeros), coefficients,
+  // and whether this wave writes the slot at all
+  unsigned efr[NED], eoff[NED];
+  int eslot[NED];
+  float ecf[NED][NE];
+  bool ewr[NED];
+  {
+    const bool lo = fw == 0, hi = fw == nlive - 1;
+    if (SOLO) {
+      efr[0] = rfr - frame4; eslot[0] = 0; eoff[0] = tr > 0 ? ooff : ZC_NOWHERE; ewr[0] = true;
+      efr[NED - 1] = rfr + frame4; eslot[NED - 1] = 2; eoff[NED - 1] = tr + 1 < g.TR ? ooff : ZC_NOWHERE; ewr[NED - 1] = true;
+    } else {
+      efr[0] = lo ? rfr - frame4 : rfr + frame4;
+      eslot[0] = lo ? 0 : nlive + 1;
+      eoff[0] = (lo && tr > 0) || (hi && !lo && tr + 1 < g.TR) ? ooff : ZC_NOWHERE;
+      ewr[0] = lo || hi;
+    }
+#pragma unroll
+    for (int s = 0; s < NED; ++s) {
+      const int tre = min(max(eslot[s] == 0 ? tr - 1 : tr + 1, 0), g.TR - 1);
+#pragma unroll
+      for (int k = 0; k < NE; ++k) ecf[s][k] = up[k] * ldc(a.wt, k * g.TR + tre);
+    }
   }
 
   ZColAdjAcc<P, TG, W> acc;
@@ -442,142 +481,115 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
   eacc.N0 = g.N0; eacc.N1 = g.N1; eacc.N2 = g.N2;
   eacc.i1 = pi1;
 
-  fv hal[NE][EPT], elo[NE], ehi[NE], nxt[NE], fnx[NF];
-#pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    elo[e] = ehi[e] = nxt[e] = vec_zero<W>();
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) hal[e][j] = vec_zero<W>();
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) acc.gcol[e][i] = vec_zero<W>();
-  }
-#pragma unroll
-  for (int f = 0; f < NF; ++f) fnx[f] = acc.fq[f] = vec_zero<W>();
+  fv hal[NE][EPT], edg[NED][NE], nxt[NE], fnx[NF];
   PlaneCursor<true> cur;
-  cur.init(za + GH0 + 1, g.N0, plane);
-  if (live) {
+  cur.init(za + GH0 + 1, g.N0, 1);
+  {
     bool on;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
-      const int pz = z_plane<true>(za - GH0 + i, g.N0, on);
+      const unsigned pz = (unsigned)z_plane<true>(za - GH0 + i, g.N0, on) * plane4;
 #pragma unroll
-      for (int e = 0; e < NE; ++e) acc.gcol[e][i] = *reinterpret_cast<const fv*>(rp[e] + (long)pz * plane + ooff);
+      for (int e = 0; e < NE; ++e) acc.gcol[e][i] = BufIO<W>::load(rbuf[e], ooff, rfr + pz);
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) hal[e][j] = *reinterpret_cast<const fv*>(rp[e] + (long)za * plane + hc.goff[j]);
-    }
-    if (has_lo) {
+      for (int j = 0; j < EPT; ++j) hal[e][j] = BufIO<W>::load(rbuf[e], hc.goff[j], rfr + (unsigned)za * plane4);
 #pragma unroll
-      for (int e = 0; e < NE; ++e) elo[e] = *reinterpret_cast<const fv*>(rp[e] - g.S + (long)za * plane + ooff);
+      for (int s = 0; s < NED; ++s) edg[s][e] = BufIO<W>::load(rbuf[e], eoff[s], efr[s] + (unsigned)za * plane4);
     }
-    if (has_hi) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) ehi[e] = *reinterpret_cast<const fv*>(rp[e] + g.S + (long)za * plane + ooff);
-    }
-    if (AF) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) fnx[f] = *reinterpret_cast<const fv*>(fb[f] + (long)za * plane + ooff);
-    }
+    for (int f = 0; f < NF; ++f) fnx[f] = AF ? BufIO<W>::load(fbuf[f], ooff, fr + (unsigned)za * plane4) : vec_zero<W>();
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
 #pragma unroll
       for (int i = 0; i < NZ; ++i) acc.gcol[e][i] = acc.gcol[e][i] * cf[e];
     }
   }
-  long ko = (long)za * plane;
-  // gradients of plane k leave at the top of step k + 1, ahead of that step's loads (in-order memory counter: see the
-  // forward kernel); the gradients of the clip's first / last frame (two of the clip's waves) leave at once
-  fv gst[NF];
+  auto write_image = [&](float* img) __attribute__((always_inline)) {
+    if (!live) return;
+    float* mine = img + (fw + 1) * NE * TG::SIZE;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) gst[f] = vec_zero<W>();
-  const long gown = (long)pi1 * g.N2 + pi2;
+    for (int e = 0; e < NE; ++e) {
+      *reinterpret_cast<fv*>(mine + e * TG::SIZE + olds) = acc.gcol[e][GH0];
+#pragma unroll
+      for (int j = 0; j < EPT; ++j)
+        if (hc.lds[j] >= 0) *reinterpret_cast<fv*>(mine + e * TG::SIZE + hc.lds[j]) = hal[e][j] * cf[e];
+#pragma unroll
+      for (int s = 0; s < NED; ++s)
+        if (ewr[s]) *reinterpret_cast<fv*>(img + (eslot[s] * NE + e) * TG::SIZE + olds) = edg[s][e] * ecf[s][e];
+    }
+  };
+  write_image(s_img);
+  unsigned ko = (unsigned)za * plane4;
 
   for (int k = za; k < zb; ++k) {
     float* img = s_img + ((k - za) & 1) * bufsz;
-    float* mine = img + (fw + 1) * NE * TG::SIZE;
-    if (live) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        *reinterpret_cast<fv*>(mine + e * TG::SIZE + olds) = acc.gcol[e][GH0];
+    for (int f = 0; f < NF; ++f) acc.fq[f] = fnx[f];
+    __syncthreads();
+    const unsigned kn = k + 1 < zb ? ko + plane4 : ko;
+#ifndef PDE_AMD_ZC_NOLOAD
 #pragma unroll
-        for (int j = 0; j < EPT; ++j)
-          if (hc.lds[j] >= 0) *reinterpret_cast<fv*>(mine + e * TG::SIZE + hc.lds[j]) = hal[e][j] * cf[e];
-      }
-      if (first) {      // the slot before the group's first frame: a residual frame of the previous group, or nothing
+    for (int e = 0; e < NE; ++e) {
+      nxt[e] = BufIO<W>::load(rbuf[e], ooff, rfr + (unsigned)cur.p * plane4);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) *reinterpret_cast<fv*>(img + e * TG::SIZE + olds) = has_lo ? elo[e] * cflo[e] : vec_zero<W>();
-      }
-      if (last) {
+      for (int j = 0; j < EPT; ++j) hal[e][j] = BufIO<W>::load(rbuf[e], hc.goff[j], rfr + kn);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) *reinterpret_cast<fv*>(mine + (NE + e) * TG::SIZE + olds) = has_hi ? ehi[e] * cfhi[e] : vec_zero<W>();
-      }
-      if (inside && k > za) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) __builtin_nontemporal_store(gst[f], reinterpret_cast<fv*>(gb[f] + gown + ko - plane));
-      }
+      for (int s = 0; s < NED; ++s) edg[s][e] = BufIO<W>::load(rbuf[e], eoff[s], efr[s] + kn);
     }
     if (AF) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) acc.fq[f] = fnx[f];
+      for (int f = 0; f < NF; ++f) fnx[f] = BufIO<W>::load(fbuf[f], ooff, fr + kn);
     }
-    __syncthreads();
-    const bool more = k + 1 < zb;
-    if (live && more) {
+#else      // ablation (wrong results): no global loads inside the loop
 #pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        nxt[e] = *reinterpret_cast<const fv*>(rp[e] + cur.off + ooff);
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) hal[e][j] = *reinterpret_cast<const fv*>(rp[e] + ko + plane + hc.goff[j]);
-      }
-      if (has_lo) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) elo[e] = *reinterpret_cast<const fv*>(rp[e] - g.S + ko + plane + ooff);
-      }
-      if (has_hi) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) ehi[e] = *reinterpret_cast<const fv*>(rp[e] + g.S + ko + plane + ooff);
-      }
-      if (AF) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) fnx[f] = *reinterpret_cast<const fv*>(fb[f] + ko + plane + ooff);
-      }
-    }
-    cur.advance(g.N0, plane);
-    if (live && inside) {
+    for (int e = 0; e < NE; ++e) nxt[e] = acc.gcol[e][0];
+#endif
+    cur.advance(g.N0, 1);
+    {
       acc.i0 = k;
-      acc.site = mine + olds;
+      acc.site = img + (fw + 1) * NE * TG::SIZE + olds;
+      fv out[NF];
 #pragma unroll
       for (int px = 0; px < W; ++px) {
         acc.px = px; acc.i2 = pi2 + px;
         float gr[NF];
+#ifdef PDE_AMD_ZC_NOCOMP      // ablation (wrong results): a few taps instead of the adjoint
+#pragma unroll
+        for (int f = 0; f < NF; ++f) gr[f] = acc.G(f % NE, 0, -GH0, 0, 0) + acc.G(f % NE, 0, GH0, 0, 0) + acc.G(f % NE, 0, 0, 1, 0) + acc.G(f % NE, 1, 0, 0, 0) + acc.F(f, 0, 0, 0, 0);
+#else
         P::adjoint(acc, gr);
+#endif
 #pragma unroll
-        for (int f = 0; f < NF; ++f) gst[f][px] = gr[f];
+        for (int f = 0; f < NF; ++f) out[f][px] = gr[f];
       }
-      // the clip's first / last frame: the time share of this residual frame alone
-      if (tr == 0 || tr == g.TR - 1) {
-        eacc.i0 = k;
+#ifndef PDE_AMD_ZC_NOSTORE
 #pragma unroll
-        for (int e = 0; e < NE; ++e) eacc.gq[e] = acc.gcol[e][GH0];
+      for (int f = 0; f < NF; ++f) BufIO<W>::store_nt(out[f], gbuf[f], soff, fr + ko);
+#endif
+      // the clip's first / last frame: the time share of this residual frame alone; every wave evaluates the few terms,
+      // the stores of all but the first / last residual frame's waves go nowhere
+      eacc.i0 = k;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s == 0 ? tr != 0 : tr != g.TR - 1) continue;
-          eacc.side = s == 0 ? 1 : -1;
-          fv est[NF];
+      for (int e = 0; e < NE; ++e) eacc.gq[e] = acc.gcol[e][GH0];
 #pragma unroll
-          for (int px = 0; px < W; ++px) {
-            eacc.px = px; eacc.i2 = pi2 + px;
-            float gr[NF];
-            P::adjoint_time(eacc, gr);
+      for (int s = 0; s < 2; ++s) {
+        eacc.side = s == 0 ? 1 : -1;
+        fv est[NF];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) est[f][px] = gr[f];
-          }
-          const long shift = s == 0 ? -g.S : g.S;
+        for (int px = 0; px < W; ++px) {
+          eacc.px = px; eacc.i2 = pi2 + px;
+          float gr[NF];
+          P::adjoint_time(eacc, gr);
 #pragma unroll
-          for (int f = 0; f < NF; ++f) __builtin_nontemporal_store(est[f], reinterpret_cast<fv*>(gb[f] + shift + gown + ko));
+          for (int f = 0; f < NF; ++f) est[f][px] = gr[f];
         }
+#ifndef PDE_AMD_ZC_NOSTORE
+#pragma unroll
+        for (int f = 0; f < NF; ++f) BufIO<W>::store_nt(est[f], gbuf[f], s == 0 ? soff_first : soff_last, (s == 0 ? fr - frame4 : fr + frame4) + ko);
+#endif
       }
     }
 #pragma unroll
@@ -586,11 +598,8 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
       for (int i = 0; i + 1 < NZ; ++i) acc.gcol[e][i] = acc.gcol[e][i + 1];
       acc.gcol[e][NZ - 1] = nxt[e] * cf[e];
     }
-    ko += plane;
-  }
-  if (live && inside && zb > za) {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) __builtin_nontemporal_store(gst[f], reinterpret_cast<fv*>(gb[f] + gown + ko - plane));
+    ko += plane4;
+    write_image(s_img + ((k + 1 - za) & 1) * bufsz);
   }
 }
 

@@ -14,8 +14,8 @@ from __future__ import annotations
 import os
 from typing import List
 
-from .expr import (Emitter, Aux, Add, Car, GRef, Ref, ZERO, UniformTable, add, collect, find_carries, footprint, hoist_uniforms,
-                   replace_subtrees, share_products)
+from .expr import (Emitter, Aux, Add, Car, GRef, Ref, ZERO, UniformTable, add, collect, factor_pointwise, find_carries, footprint,
+                   hoist_uniforms, replace_subtrees, share_products)
 from .specs import SPECS, PDE_IDS, Spec
 
 GEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", "gen")
@@ -143,6 +143,7 @@ def emit_spec(s: Spec) -> str:
     L.append(f"  static constexpr int ZCOL = {1 if s.zcol else 0}, ZPURE = {1 if s.z_pure else 0}, ZCT1 = {s.zc_tile[0]}, ZCT2 = {s.zc_tile[1]}, ZCW = {s.zc_width}, ZCWB = {s.zc_width_bwd}, ZCOLV = {1 if s.zcol_plain_fwd else 0};")
     L.append(f"  static constexpr const char* NAME = \"{s.name}\";")
     parts = [split_adjoint(e) for e in s.adjoint]
+    fa = (lambda e: factor_pointwise(e)) if s.factor_adjoint else (lambda e: e)
     time_f = footprint([p[1] for p in parts], Ref)["count"]
     tuse = [0] * nf
     for r in s.residuals:
@@ -154,8 +155,8 @@ def emit_spec(s: Spec) -> str:
     L.append(f"  static constexpr int TIME_AF = {1 if time_f else 0};   // the other-frame adjoint terms read fields")
     tab = UniformTable() if s.hoist_uniforms else None
     body = _emit_fn("residual", "R", ne, s.residuals, tab=tab, share=True)
-    body += _emit_fn("adjoint", "g", nf, s.adjoint, tab=tab)
-    body += _emit_fn("adjoint_space", "g", nf, [p[0] for p in parts], tab=tab)
+    body += _emit_fn("adjoint", "g", nf, [fa(e) for e in s.adjoint], tab=tab)
+    body += _emit_fn("adjoint_space", "g", nf, [fa(p[0]) for p in parts], tab=tab)
     ncar, lines = _emit_carry_fns(s.residuals, [p[0] for p in parts], ne, nf, s.carry_max, tab=tab)
     body += lines
     body += _emit_fn("adjoint_time", "g", nf, [p[1] for p in parts], tab=tab)

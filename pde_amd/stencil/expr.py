@@ -616,6 +616,82 @@ def share_products(exprs: List[E]) -> List[E]:
     return [regroup(e, memo) for e in exprs]
 
 
+# ---------------------------------------------------------------------------
+# adjoint regrouped around the field values at the output point
+# ---------------------------------------------------------------------------
+# adjoint_exprs() yields one term per tap of a scaled residual, each with its own coefficient expression:
+#     G(+1) * (-(8 c u) - l)  +  G(-1) * ((8 c u) - l)  +  G(+2) * (c u)  - ...
+# Where the coefficients are polynomials in field values AT THE OUTPUT POINT (conservative products such as d(phi u)/dx),
+# the same sum ordered by those field values is a few plain stencils of G with uniform weights, each scaled once:
+#     u * (c G(+2) - 8c G(+1) + 8c G(-1) - c G(-2))  +  (-l G(+1) - l G(-1) + ...)
+# i.e. one multiply-add per tap with a hoisted uniform weight, instead of two or three operations per tap.
+
+def _monomials(e: E, limit: int = 4096):
+    """e as a list of (number, tuple of atomic factors) whose sum of products equals e; None when the expansion would
+    exceed `limit` monomials.  Everything but Add, Mul and Num is atomic."""
+    if isinstance(e, Num):
+        return [(e.v, ())]
+    if isinstance(e, Add):
+        out = []
+        for t in e.terms:
+            m = _monomials(t, limit)
+            if m is None:
+                return None
+            out += m
+            if len(out) > limit:
+                return None
+        return out
+    if isinstance(e, Mul):
+        out = [(1.0, ())]
+        for f in e.factors:
+            m = _monomials(f, limit)
+            if m is None or len(out) * len(m) > limit:
+                return None
+            out = [(c1 * c2, a1 + a2) for c1, a1 in out for c2, a2 in m]
+        return out
+    return [(1.0, (e,))]
+
+
+def factor_pointwise(e: E) -> E:
+    """The adjoint expression e regrouped as  sum over products P of output-point values  P * (sum_i w_i G_i)  with uniform
+    weights w_i; e itself when it does not have that shape (a term without exactly one scaled residual, a field value
+    away from the output point or frame, an expansion that explodes) or when the regrouped form has no fewer operations."""
+    mons = _monomials(e)
+    if mons is None:
+        return e
+    groups: Dict[object, Dict[object, list]] = {}
+    order: List[object] = []
+    points: Dict[object, Tuple[E, ...]] = {}
+    for c, atoms in mons:
+        if c == 0.0:
+            continue
+        gs = [a for a in atoms if isinstance(a, GRef)]
+        if len(gs) != 1:
+            return e
+        uni = sorted((a for a in atoms if isinstance(a, (Par, Uni))), key=lambda a: a.key())
+        pts = sorted((a for a in atoms if not isinstance(a, (Par, Uni, GRef))), key=lambda a: a.key())
+        for a in pts:      # only values at the output point and frame may be pulled out of the tap sums
+            for r in collect(a, Ref).values():
+                if r.ot != 0 or r.o != ZERO3:
+                    return e
+            if collect(a, GRef):
+                return e
+        pk = tuple(a.key() for a in pts)
+        if pk not in groups:
+            groups[pk] = {}
+            order.append(pk)
+            points[pk] = tuple(pts)
+        slot = groups[pk].setdefault((gs[0].key(), tuple(a.key() for a in uni)), [0.0, gs[0], uni])
+        slot[0] += c
+    terms = []
+    for pk in order:
+        taps = [mul(Num(c), *uni, g) for c, g, uni in groups[pk].values() if c != 0.0]
+        if taps:
+            terms.append(mul(*points[pk], add(*taps)))
+    res = add(*terms) if terms else ZERO
+    return res if op_count(res) < op_count(e) else e
+
+
 def replace_subtrees(e: E, table: Dict[object, E], memo=None) -> E:
     if memo is None:
         memo = {}

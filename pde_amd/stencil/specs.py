@@ -65,6 +65,7 @@ class Spec:
     hoist_uniforms: bool = True     # precompute products/sums of constants and per-sample parameters once per sample
     quad_prefetch: int = 2          # adjoint: frames fetched this many steps ahead (2 costs one more register set)
     carry_max: int = 6              # adjoint: at most this many values per point handed from the residual stage to the gather
+    factor_adjoint: bool = False    # emit the adjoint regrouped around the field values at the output point (expr.factor_pointwise)
 
     # derived
     def analyse(self):
@@ -510,7 +511,7 @@ def _ape_burgers3d():
         res.append(_ddt(b, phi) + b1 * conv - a2 * lap(phi))
     # per-frame kernels (the time ring of 3-D halo tiles does not fit LDS): a near-cubic tile reads 3.4 halo floats per
     # point instead of 5.1 and leaves room for three workgroups per CU
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zcol_plain_fwd": True, "zc_width": 4, "zc_width_bwd": 2})
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zcol_plain_fwd": True, "zc_width": 4, "zc_width_bwd": 2, "zc_tile": (4, 64), "factor_adjoint": True})
 
 
 def _swift_hohenberg3d():

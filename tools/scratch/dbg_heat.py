@@ -1,0 +1,45 @@
+import sys, torch
+sys.path.insert(0, ".")
+import pde_amd
+from pde_amd import functional as PF
+PF.SMALL_FIELD_ELEMENTS = 0
+dev = torch.device("cuda:0")
+shape = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (2, 9, 128, 128, 128)
+g = torch.Generator().manual_seed(1)
+u = torch.randn(shape, generator=g).to(dev)
+al = torch.rand(shape[0], generator=g).to(dev) * 0.04 + 0.005
+fn = pde_amd.Heat3DPDELoss().to(dev) if not hasattr(pde_amd.Heat3DPDELoss, "defaults") else pde_amd.Heat3DPDELoss().to(dev)
+out = {}
+for mode in ("stored", "recompute"):
+    fn.backward_mode = mode
+    x = u.clone().requires_grad_(True)
+    t, _ = fn(x, alpha=al)
+    t.backward()
+    out[mode] = x.grad
+    print(mode, float(t), PF.HipBackend.last_adjoint_kernel)
+d = (out["stored"] - out["recompute"]).abs()
+print("max", float(d.max()), "gmax", float(out["recompute"].abs().max()))
+bad = d > 1e-6 * float(out["recompute"].abs().max())
+print("bad count", int(bad.sum()), "of", bad.numel())
+for dim, name in enumerate("b t z y x".split()):
+    other = [i for i in range(5) if i != dim]
+    cnt = bad.sum(dim=other)
+    print(name, [int(c) for c in cnt.tolist()] if cnt.numel() <= 16 else ([i for i, c in enumerate(cnt.tolist()) if c][:40], "nonzero idx"))
+idx = bad.nonzero()[:12]
+if len(idx) == 0:
+    sys.exit(0)
+s, r = out["stored"], out["recompute"]
+for i in idx.tolist():
+    b, t, z, y, x = i
+    print(i, "stored", [round(float(v), 6) for v in s[b, t, z, y, x - 1:x + 5]], "want", [round(float(v), 6) for v in r[b, t, z, y, x - 1:x + 5]])
+# is the wrong value some other point's right value?
+b, t, z, y, x = idx[0].tolist()
+v = s[b, t, z, y, x]
+hit = ((r - v).abs() < 1e-9).nonzero()[:5]
+print("value found at", hit.tolist())
+fn.backward_mode = "stored"
+x2 = u.clone().requires_grad_(True)
+t2, _ = fn(x2, alpha=al)
+t2.backward()
+print("deterministic", bool(torch.equal(x2.grad, s)), int(((x2.grad - r).abs() > 1e-6 * float(r.abs().max())).sum()))
+print(bad.nonzero().tolist()[:64])
