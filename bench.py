@@ -1,6 +1,7 @@
 """Benchmark: fused PDE-residual loss forward+backward, Taylor-Green 2-D, B=16 T=16 256x256 per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rotate K]
+    python bench.py --gpus N --case gray_scott --strong      (64 Gray-Scott samples split over the ranks)
 
 One step = one TaylorGreen2DPDELoss forward + backward over one batch of synthetic fields already
 resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 16 samples (weak scaling)
@@ -118,6 +119,7 @@ def last_adjoint_kernel():
 def other_case_table(dev):
     U = lambda b, lo, hi: lo + (hi - lo) * torch.rand(b, device=dev)
     return [
+        ("Burgers 1-D B=20, [20,9,256] x1", "Burgers1DPDELoss", {}, (20, 9, 256), lambda b: dict(nu=U(b, 0.005, 0.05))),
         ("Rayleigh-Benard B=64, [64,9,512,128] x3", "RayleighBenardFullPDELoss", {}, (64, 9, 512, 128), lambda b: dict(kappa=U(b, 1e-4, 1e-2))),
         ("shear flow n-PINN B=64, [64,9,256,512] x4", "ShearFlowPDELossNPINN", {}, (64, 9, 256, 512), lambda b: {}),
         ("Gray-Scott FD-c4, 8 samples per GPU, [8,9,128,128] x2", "GrayScottPDELoss", dict(laplacian="fd4"), (8, 9, 128, 128), lambda b: {}),
@@ -180,10 +182,141 @@ def run_other_cases(dev, launches=16):
         if k_ms:
             avg = sum(k_ms) / len(k_ms)
             rec.update(avg_ms=avg, frac=8 * e_in / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        # the same step replayed as a HIP graph (loss_fn.capture): what a training loop pays once the host's launch work
+        # is out of the way, which is most of an eager step of the small configurations
+        try:
+            cap = mod.capture(*fields, **pk)
+            for _ in range(8):
+                cap()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(4 * launches):
+                cap()
+            b.record()
+            torch.cuda.synchronize()
+            rec["replayed_ms_per_step"] = a.elapsed_time(b) / (4 * launches)
+            del cap
+        except Exception as e:      # capture unsupported here
+            rec["replayed_ms_per_step"] = None
+            rec["replay_error"] = f"{type(e).__name__}: {e}"[:200]
         out.append(rec)
         del fields, mod
         torch.cuda.empty_cache()
     return out
+
+
+GS_TOTAL, GS_T, GS_N = 64, 9, 128      # Gray-Scott as the reference runs it: 64 samples of 128 x 128, split over the ranks
+
+
+def gray_scott_strong(args, world, rank, dev, distributed):
+    """`--case gray_scott --strong`: the Gray-Scott residual loss fwd+bwd on 64 samples in total, 64 / N per rank (strong
+    scaling), with the reference's spectral Laplacian ('fft') and with the 4th-order stencil ('fd4').  A step is the
+    module call + backward replayed as one HIP graph (loss_fn.capture()); its loss scalars go through one packed
+    all-reduce per window of steps.  Prints one JSON line: `value` is the spectral variant's global grid-points/s."""
+    import torch.distributed as dist
+    from pde_amd.stencil.specs import SPECS
+    if GS_TOTAL % world:
+        print(f"bench: {GS_TOTAL} samples do not split evenly over {world} ranks", file=sys.stderr)
+        return 2
+    b = GS_TOTAL // world
+    backend = PF.get_backend()
+    window = max(1, args.reduce_window)
+    variants = {}
+    for lap in ("fft", "fd4"):
+        mod = pde_amd.GrayScottPDELoss(laplacian=lap).to(dev)
+        mod.backward_mode = "fused"
+        spec = SPECS[mod.SPEC]
+        gen = torch.Generator(device=dev).manual_seed(77 + rank)
+        fields = [(0.5 + 0.25 * torch.rand((b, GS_T, GS_N, GS_N), device=dev, generator=gen)).requires_grad_(True) for _ in range(2)]
+        names = [*mod.EQS, "total"]
+        win = pdist.ScalarWindow(names, window, dev, force=distributed)
+        staging = torch.zeros(len(names), device=dev)
+        mod.scalars_out = staging
+        try:
+            step_fn = mod.capture(*fields)
+            launch = "hip-graph replay (loss_fn.capture)"
+        except Exception as e:      # capture unsupported here: eager steps
+            print(f"bench: HIP graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            launch = "eager"
+
+            def step_fn():
+                for f in fields:
+                    f.grad = None
+                total, losses = mod(*fields)
+                total.backward(gradient=mod.upstream_scalar(dev))
+                return total, losses
+
+        def run(k_steps):
+            for i in range(k_steps):
+                win.before(i)
+                step_fn()
+                win.row(i).copy_(staging)
+                win.after(i)
+            win.flush(k_steps)
+            return win.drain()
+
+        run(max(args.warmup, 2 * window))
+        if distributed and lap == "fft":
+            pdist.reduce_packed_async(["x"], torch.zeros(1, device=dev), force=True).result()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < args.settle_ms:      # working clocks
+            for _ in range(16):
+                step_fn()
+            torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        red = {k: v[-1] for k, v in run(args.steps)[-1][1].items()}
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax)
+        pts = GS_TOTAL * (GS_T - spec.tlo - spec.thi) * GS_N * GS_N
+        rec = {"value": pts / (elapsed / args.steps), "ms_per_step": elapsed / args.steps * 1e3, "launch": launch,
+               "loss": float(red["total"])}
+        # the stencil adjoint's launch time, from a few eager steps with the library's events around that launch
+        kev = []
+        mod.scalars_out = None
+        backend.backward_events, backend.forward_events = kev, None
+        try:
+            for _ in range(16):
+                for f in fields:
+                    f.grad = None
+                total, _ = mod(*fields)
+                total.backward(gradient=mod.upstream_scalar(dev))
+        finally:
+            backend.backward_events = backend.forward_events = None
+        torch.cuda.synchronize()
+        k_ms = sorted(x.elapsed_time(y) for x, y in kev)
+        if k_ms:
+            e_in = (4 if lap == "fft" else 2) * b * GS_T * GS_N * GS_N      # fft: the two Laplacian fields are inputs of the kernel too
+            avg = sum(k_ms) / len(k_ms)
+            rec["roofline"] = {"bound": "hbm", "kernel": last_adjoint_kernel(), "achieved": 8 * e_in / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": 8 * e_in / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": 8 * e_in,
+                               "avg_ms": avg, "timed_launches": len(k_ms),
+                               "note": "the pointwise/stencil adjoint launch of one rank's share; the spectral variant's transforms are rocFFT launches beside it"}
+        variants[lap] = rec
+        del fields, mod, step_fn
+        torch.cuda.empty_cache()
+    if rank == 0:
+        main_v = variants["fft"]
+        out = {"metric": "PDE-residual loss fwd+bwd grid-points/sec", "value": main_v["value"], "unit": "grid-points/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_v["ms_per_step"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"Gray-Scott 2D reaction-diffusion residual fwd+bwd, B={GS_TOTAL} in total ({b} per GPU), T={GS_T}, "
+                                      f"{GS_N}x{GS_N}, 2 fields, spectral Laplacian (value) and 4th-order stencil (variants.fd4)",
+                          "parallelism": f"dp{world}", "launch": main_v["launch"], "backward_mode": "fused"},
+               "roofline": main_v.get("roofline"), "variants": variants, "loss": main_v["loss"]}
+        if world > 1 or distributed:
+            out["rccl_world_size"] = dist.get_world_size()
+        print(json.dumps(out))
+    return 0
 
 
 def launch_command(gpus, argv, port, python=None):
@@ -225,6 +358,10 @@ def parse_args(argv=None):
     ap.add_argument("--reduce-window", type=int, default=8,
                     help="steps whose logging scalars share one all-reduce (dist.ScalarWindow); 1 = a collective every step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--case", default="taylor_green", choices=["taylor_green", "gray_scott"],
+                    help="taylor_green: the headline configuration, B=16 per GPU (weak scaling); gray_scott (with --strong): the "
+                         "reference's Gray-Scott configuration, 64 samples split over the ranks")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the total batch is fixed and split over the ranks (--case gray_scott)")
     ap.add_argument("--dry", action="store_true",
                     help="rehearse the launcher, the rendezvous and the packed all-reduce without a GPU: no kernel runs, "
                          "the printed value is 0 and the line carries \"dry\": true (use with --backend gloo)")
@@ -278,6 +415,9 @@ def main(argv=None):
     if world != args.gpus:
         print(f"bench: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus must be the world size", file=sys.stderr)
         return 2
+    if (args.case == "gray_scott") != args.strong:
+        print("bench: --case gray_scott is the strong-scaling configuration and --strong belongs to it: pass both or neither", file=sys.stderr)
+        return 2
     if args.dry:
         dry_run(args, world, rank)
         return 0
@@ -288,6 +428,12 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group(args.backend, device_id=dev)
         assert dist.get_world_size() == world
+
+    if args.case == "gray_scott":
+        rc = gray_scott_strong(args, world, rank, dev, distributed)
+        if distributed:
+            dist.destroy_process_group()
+        return rc
 
     n_sets = max(1, args.rotate)
     sets = []

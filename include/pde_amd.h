@@ -279,6 +279,19 @@ int pde_amd_scatter_field_grads_affine(const float* const* field_grads, int64_t 
                                        const int32_t* channels, int32_t n_fields, int32_t rows, int32_t cols, int32_t transpose,
                                        const float* scale, float* grad_output, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Spectral Laplacian of two real fields at once (the Gray-Scott loss's fft_laplacian,
+ * finetune/pde_loss_verified.py:200-214, applied to A and to B at :226-227 of the same file):
+ *   lap = ifft2(multiplier * fft2(f)).real over the last two axes, multiplier = -K2 of shape [nx][ny].
+ * a, b, lap_a, lap_b: [planes][nx][ny] fp32, 16-byte aligned; a plane pair (a[p], b[p]) is transformed as one complex
+ * plane inside one workgroup's LDS.  The multiplier must be real and even in both wavenumbers (K2 is), which also makes
+ * the operator its own adjoint: the backward pass calls the same entry point on the two upstream gradients.
+ * nx, ny in {16, 32, 64, 128}; anything else returns PDE_AMD_ESHAPE (pde_amd_spectral_pair_supported tells beforehand)
+ * and the caller keeps its rocFFT path. */
+int pde_amd_spectral_pair_supported(int32_t nx, int32_t ny);
+int pde_amd_spectral_laplacian_pair(const float* a, const float* b, float* lap_a, float* lap_b, const float* multiplier,
+                                    int64_t planes, int32_t nx, int32_t ny, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ Drop-in classes and functions carrying the signatures of reca1c1trant/PDE's loss
 arithmetic runs in hand-written HIP kernels behind a C ABI (include/pde_amd.h).
 """
 from .losses import (  # noqa: F401
-    StencilPDELoss, Burgers1DPDELoss, Advection1DPDELoss, Heat1DPDELoss, APEBenchBurgers1DPDELoss, KS1DPDELoss,
+    StencilPDELoss, CapturedLossStep, Burgers1DPDELoss, Advection1DPDELoss, Heat1DPDELoss, APEBenchBurgers1DPDELoss, KS1DPDELoss,
     KdV1DPDELoss, TaylorGreen2DPDELoss, AdvDiff2DPDELoss, AnisoDiff2DPDELoss, Wave2DPDELoss,
     APEBenchBurgers2DPDELoss, NSPwCPDELoss, KP2DPDELoss, ShearFlowPDELossNPINN, ShearFlowPDELoss, Burgers2DCHPDELoss,
     ActiveMatterNPINNPDELoss, RayleighBenardFullPDELoss, TurbulentRadiativePDELoss, WaveGaussPDELoss,

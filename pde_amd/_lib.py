@@ -98,6 +98,9 @@ SIGNATURES = {
     "pde_amd_scatter_field_grads": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                               C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p]),
+    "pde_amd_spectral_pair_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "pde_amd_spectral_laplacian_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                                  C.c_int32, C.c_void_p]),
 }
 
 

@@ -318,7 +318,7 @@ struct Ops {
       }
       bool launched = false;
       if constexpr (ZColCfg<P, P::ZCW>::FWD_OK) {
-        if (zcol_usable(p, fields) && aligned_vec<P::NE, P::ZCW>(resid_out)) {
+        if (P::ZCOLF != 0 && zcol_usable(p, fields) && aligned_vec<P::NE, P::ZCW>(resid_out)) {
           items = launch_zcol_forward<true>(p, a, tr, cap, stream);
           if (items == -2) return PDE_AMD_EWORKSPACE;
           if (items == -1) return PDE_AMD_ESHAPE;
@@ -649,8 +649,13 @@ struct Ops {
 #define PDE_AMD_DIAG_ZCT1 PDE_AMD_DIAG_ONLY::ZCT1
 #define PDE_AMD_DIAG_ZCT2 PDE_AMD_DIAG_ONLY::ZCT2
 #endif
+#ifndef PDE_AMD_DIAG_ZCOL
+#define PDE_AMD_DIAG_ZCOL PDE_AMD_DIAG_ONLY::ZCOL
+#define PDE_AMD_DIAG_ZCOLF PDE_AMD_DIAG_ONLY::ZCOLF
+#endif
 struct DiagPde : PDE_AMD_DIAG_ONLY {
   static constexpr int ZCW = PDE_AMD_DIAG_ZCW, ZCWB = PDE_AMD_DIAG_ZCWB, ZCT1 = PDE_AMD_DIAG_ZCT1, ZCT2 = PDE_AMD_DIAG_ZCT2;
+  static constexpr int ZCOL = PDE_AMD_DIAG_ZCOL, ZCOLF = PDE_AMD_DIAG_ZCOLF;
 };
 #define PDE_AMD_VT(P) Ops<DiagPde>::vtable(),
 #else

@@ -424,6 +424,54 @@ class _ResidualsInGraph(torch.autograd.Function):
         return (None, None, None, None, *out)
 
 
+def spectral_pair_supported(nx: int, ny: int) -> bool:
+    """whether the LDS-resident spectral Laplacian kernel takes planes of nx x ny points"""
+    return bool(_lib.lib().pde_amd_spectral_pair_supported(int(nx), int(ny)))
+
+
+def _spectral_pair_apply(a: torch.Tensor, b: torch.Tensor, mult: torch.Tensor):
+    if not (a.is_cuda and b.is_cuda and mult.is_cuda):
+        raise RuntimeError("pde_amd: the spectral Laplacian kernel needs tensors on a HIP device; there is no CPU fallback")
+    a, b = a.contiguous(), b.contiguous()
+    nx, ny = a.shape[-2], a.shape[-1]
+    if a.shape != b.shape or a.dtype is not torch.float32 or b.dtype is not torch.float32 or tuple(mult.shape) != (nx, ny):
+        raise ValueError(f"spectral Laplacian: two fp32 fields of one shape and a multiplier [{nx}, {ny}] expected")
+    la, lb = torch.empty_like(a), torch.empty_like(b)
+    planes = a.numel() // (nx * ny)
+    with torch.cuda.device(a.device):
+        stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        _lib.check(_lib.lib().pde_amd_spectral_laplacian_pair(a.data_ptr(), b.data_ptr(), la.data_ptr(), lb.data_ptr(), mult.data_ptr(),
+                                                              planes, nx, ny, stream), "spectral_laplacian_pair")
+    return la, lb
+
+
+class _SpectralLaplacianPair(torch.autograd.Function):
+    """(A, B) -> (ifft2(m * fft2(A)).real, ifft2(m * fft2(B)).real) for a real multiplier m that is even in both
+    wavenumbers (the reference's -K2, finetune/pde_loss_verified.py:200-214): such an operator is symmetric, so the
+    backward pass applies it to the two upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, a, b, mult):
+        ctx.save_for_backward(mult)
+        return _spectral_pair_apply(a.detach(), b.detach(), mult)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (mult,) = ctx.saved_tensors
+        if ga is None and gb is None:
+            return None, None, None
+        ga = torch.zeros_like(gb) if ga is None else ga
+        gb = torch.zeros_like(ga) if gb is None else gb
+        xa, xb = _spectral_pair_apply(ga, gb, mult)
+        return xa, xb, None
+
+
+def spectral_laplacian_pair(a: torch.Tensor, b: torch.Tensor, multiplier: torch.Tensor):
+    """Spectral Laplacians of two fp32 fields [..., nx, ny] in one launch (both planes of a sample and frame share one
+    complex transform in LDS); differentiable.  `multiplier`: [nx, ny] fp32, real and even in both wavenumbers."""
+    return _SpectralLaplacianPair.apply(a, b, multiplier)
+
+
 def residual_losses_and_fields(prob: StencilProblem, fields: Sequence[torch.Tensor], weights: torch.Tensor,
                                sparams: Sequence[torch.Tensor] = (), aux: Sequence[torch.Tensor] = ()):
     """residual_losses plus the residual fields themselves, in the autograd graph like the reference's

@@ -16,7 +16,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functional import StencilProblem, residual_fields, residual_losses, residual_losses_and_fields, totals_into
+from .functional import (StencilProblem, residual_fields, residual_losses, residual_losses_and_fields, spectral_laplacian_pair,
+                         spectral_pair_supported, totals_into)
 from .stencil.specs import SPECS
 
 Tensor = torch.Tensor
@@ -251,6 +252,12 @@ class StencilPDELoss(nn.Module):
         finally:
             self._capture = None
 
+    def capture(self, *fields: Tensor, warmup: int = 2, pool=None, **kwargs) -> "CapturedLossStep":
+        """Record `total, losses = self(*fields, **kwargs); total.backward()` as one HIP graph and return the object that
+        replays it: the small configurations are bound by the host's launch work (a few launches and the autograd
+        bookkeeping per step), a replay costs one launch.  See CapturedLossStep for what stays fixed between replays."""
+        return CapturedLossStep(self, fields, kwargs, warmup=warmup, pool=pool)
+
     def _buf(self, name, make, device):
         key = (name, str(device))
         if key not in self._wt_cache:
@@ -262,6 +269,56 @@ class StencilPDELoss(nn.Module):
         if key not in self._wt_cache:
             self._wt_cache[key] = torch.zeros((), dtype=torch.float32, device=device)
         return self._wt_cache[key]
+
+
+class CapturedLossStep:
+    """`step = loss_fn.capture(u, v, p, nu=nu)`; then `total, losses = step()` replays forward + backward.
+
+    The graph reads the tensors it was captured with, at their addresses: write new inputs INTO them
+    (`u.copy_(new_u)`, or let the producer write there), do not rebind them.  Fields that require gradients are leaves of
+    the captured step; after a replay their gradients of `upstream_hint * total` stand in `step.grads` (the same tensors
+    every time, also reachable as `field.grad`), and `total` / `losses` are the same tensors every time with new values.
+    A model whose output feeds the loss continues with `prediction.backward(gradient=step.grads[i])`.  The module's
+    settings at capture time (backward_mode, scales, weights, scalars_out) are part of the graph; capture again after
+    changing them.  Replays on one GPU must not overlap (they share the gradient and workspace buffers)."""
+
+    def __init__(self, loss_fn: "StencilPDELoss", fields: Sequence[Tensor], kwargs: dict, warmup: int = 2, pool=None):
+        if not fields or not all(torch.is_tensor(f) and f.is_cuda for f in fields):
+            raise RuntimeError("capture(): the fields must be tensors on a HIP device (a graph replays GPU work only)")
+        self.loss_fn, self.fields, self.kwargs = loss_fn, list(fields), dict(kwargs)
+        dev = fields[0].device
+        self._upstream = loss_fn.upstream_scalar(dev)
+        needs = [f for f in self.fields if f.requires_grad]
+        if any(not f.is_leaf for f in needs):
+            raise RuntimeError("capture(): fields that require gradients must be leaf tensors (detach the model's output into a "
+                               "buffer, capture on that buffer, and pass step.grads on to prediction.backward)")
+
+        def run():
+            for f in needs:
+                f.grad = None
+            total, losses = loss_fn(*self.fields, **self.kwargs)
+            if needs:
+                total.backward(gradient=self._upstream)
+            return total, losses
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):      # whatever a first call loads or allocates happens outside the graph
+                run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
+            self.total, self.losses = run()
+        self.grads = [f.grad for f in self.fields]
+        self.total, self.losses = self.total.detach(), {k: v.detach() for k, v in self.losses.items()}
+
+    def __call__(self):
+        self.graph.replay()
+        return self.total, self.losses
+
+    replay = __call__
 
 
 # =================================================================================================
@@ -799,8 +856,29 @@ class GrayScottPDELoss(StencilPDELoss):
         if self.laplacian == "fd4":
             return self._evaluate([A, B], reduction=reduction)
         dt = torch.float64 if A.dtype is torch.float64 and getattr(self, "_capture", None) is not None else torch.float32
-        lap = self.fft_laplacian(torch.stack([A.to(dt), B.to(dt)]))      # both fields in one batched transform
+        mult = self._pair_multiplier(A) if dt is torch.float32 and A.is_cuda and A.shape == B.shape else None
+        if mult is not None:      # both fields of a sample and frame as one complex plane, transformed inside one workgroup's LDS
+            lapA, lapB = spectral_laplacian_pair(A.to(dt), B.to(dt), mult)
+            return self._evaluate([A, B, lapA, lapB], reduction=reduction)
+        lap = self.fft_laplacian(torch.stack([A.to(dt), B.to(dt)]))      # rocFFT: both fields in one batched transform
         return self._evaluate([A, B, lap[0], lap[1]], reduction=reduction)
+
+    def _pair_multiplier(self, f: Tensor) -> Optional[Tensor]:
+        """-K2 on the fields' device when the LDS-resident transform kernel applies: plane sizes it is built for, and a
+        table that is even in both wavenumbers (the reference's always is), which the kernel's way of transforming two
+        real fields as one complex field and its backward pass rely on.  None: the rocFFT path."""
+        key = ("pair_mult", str(f.device), self.K2._version, self.K2.data_ptr())
+        hit = self._wt_cache.get(key)
+        if hit is None:
+            k2 = self.K2.detach().float().cpu()
+            nx, ny = k2.shape
+            ok = tuple(f.shape[-2:]) == (nx, ny) and spectral_pair_supported(nx, ny)
+            if ok:
+                mirror = torch.roll(torch.flip(k2, (0, 1)), (1, 1), (0, 1))      # K2[-i mod nx, -j mod ny]
+                ok = bool(torch.equal(k2, mirror))
+            hit = self._wt_cache[key] = ((-k2).contiguous().to(f.device),) if ok else (None,)
+        m = hit[0]
+        return m if m is not None and tuple(f.shape[-2:]) == tuple(m.shape) else None
 
 
 def _half_wavenumbers(n_full: int, d_full: float, n_half: int, d_half: float):

@@ -57,6 +57,7 @@ class Spec:
     # z-column kernels (csrc/stencil_zcol.hpp): a workgroup marches a (y, x) tile through z for a whole group of frames
     zcol: bool = False              # stored-residual forward and adjoint take these kernels where the PDE qualifies
     zcol_plain_fwd: bool = False    # ... and so does the forward that stores no residuals (measured per PDE)
+    zcol_stored_fwd: bool = True    # False: only the adjoint takes them, the forward that stores residuals keeps its kernel
     zc_tile: Tuple[int, int] = (8, 32)
     zc_width: int = 2               # points per lane of the forward ...
     zc_width_bwd: int = 2           # ... and of the adjoint

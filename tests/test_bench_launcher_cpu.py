@@ -37,3 +37,10 @@ def test_two_rank_gloo_dry_run():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["dry"] is True
     assert out["loss"] == 4.5                                    # last of the 4 steps: mean over the two ranks of 1 + rank + 3
+
+
+def test_strong_case_flags_go_together():
+    import bench
+    assert bench.main(["--case", "gray_scott"]) == 2
+    assert bench.main(["--strong"]) == 2
+    assert bench.parse_args(["--case", "gray_scott", "--strong", "--gpus", "4"]).strong

@@ -243,3 +243,9 @@ def test_mode_resolution_rules():
     finally:
         PF.SMALL_FIELD_ELEMENTS = small
         PF.set_backend(old)
+
+
+def test_capture_needs_device_tensors():
+    import pde_amd
+    with pytest.raises(RuntimeError, match="HIP device"):
+        pde_amd.Heat1DPDELoss().capture(torch.zeros(2, 9, 64), alpha=torch.ones(2))

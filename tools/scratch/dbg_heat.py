@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pde_amd
 from pde_amd import functional as PF
 PF.SMALL_FIELD_ELEMENTS = 0
