@@ -252,7 +252,7 @@ def _wave2d():
     u, w = b.F()
     c2 = b.s("c2")
     lap = _d2c4(b, u, 1, "dx") + _d2c4(b, u, 2, "dy")
-    return b.done([_ddt(b, u) - w, _ddt(b, w) - c2 * lap], fused_slower=True)      # [32, 9, 256^2]: one pass 0.095 ms, forward + recomputing adjoint 0.091
+    return b.done([_ddt(b, u) - w, _ddt(b, w) - c2 * lap])      # [32, 9, 256^2] replayed: one pass 0.070 ms, forward + recomputing adjoint 0.092
 
 
 def _ape_burgers2d():
@@ -385,7 +385,8 @@ def _turbulent_radiative():
     mass = _ddt(b, rho) + dx(rho * vx) + dy(rho * vy)
     xm = _ddt(b, rho * vx) + dx(rho * vx * vx + P) + dy(rho * vx * vy)
     ym = _ddt(b, rho * vy) + dx(rho * vx * vy) + dy(rho * vy * vy + P)
-    return b.done([mass, xm, ym], **{**T2D_WIDE, 'quad_prefetch': 2, 'waves_per_simd_quad': 3})
+    # [16, 9, 128, 384] replayed: stored 0.093 ms, one pass 0.096, forward + recomputing adjoint 0.119
+    return b.done([mass, xm, ym], **{**T2D_WIDE, 'quad_prefetch': 2, 'waves_per_simd_quad': 3, 'auto_stored': True, 'fused_slower': True})
 
 
 def _wave_gauss():
@@ -441,12 +442,12 @@ def _gray_scott_fd():
     ab2 = A * Bq * Bq
     ra = _ddt(b, A) - DA * lap(A) + ab2 - Fc * (1.0 - A)
     rb = _ddt(b, Bq) - DB * lap(Bq) - ab2 + Fk * Bq
-    return b.done([ra, rb], fused_slower=True)      # pointwise around rocFFT transforms, [8, 9, 128^2]: one pass 0.284 ms, forward + adjoint 0.222
+    return b.done([ra, rb])      # [64, 9, 128^2] replayed: one pass 0.051 ms, forward + recomputing adjoint 0.067
 
 
 def _gray_scott_pw():
-    # GrayScottPDELoss :216-302 with the spectral Laplacians supplied as two extra fields
-    # (computed by rocFFT through torch.fft): pointwise residual + reduction only
+    # GrayScottPDELoss :216-302 with the spectral Laplacians supplied as two extra fields (the LDS-resident transform
+    # kernel, or rocFFT for plane sizes it is not built for): pointwise residual + reduction only
     b = _B("gray_scott_pw", 2, ["A", "B", "lapA", "lapB"], ["A_equation", "B_equation"])
     A, Bq, lA, lB = b.F()
     DA, DB = b.c("D_A", _k("D_A")), b.c("D_B", _k("D_B"))
@@ -454,7 +455,7 @@ def _gray_scott_pw():
     ab2 = A * Bq * Bq
     ra = _ddt(b, A) - DA * lA + ab2 - Fc * (1.0 - A)
     rb = _ddt(b, Bq) - DB * lB - ab2 + Fk * Bq
-    return b.done([ra, rb], fused_slower=True)      # pointwise around rocFFT transforms, [8, 9, 128^2]: one pass 0.284 ms, forward + adjoint 0.222
+    return b.done([ra, rb])      # with the spectral Laplacian kernel, [64, 9, 128^2] replayed: one pass 0.223 ms, forward + adjoint 0.244
 
 
 def _active_matter_fft():

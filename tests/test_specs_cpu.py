@@ -237,8 +237,7 @@ def test_mode_resolution_rules():
         assert PF.resolve_mode("fused", "tg2d") == "fused"                       # size unknown: no rule
         assert PF.resolve_mode("fused", "burgers1d", 1000) == "fused"            # 1-D clips are launch-bound either way
         assert PF.resolve_mode("recompute", "tg2d", 1000) == "recompute"         # an explicit mode is kept
-        assert PF.resolve_mode("fused", "wave2d", big) == "recompute"            # fused_slower
-        assert PF.resolve_mode("fused", "gray_scott_pw", big) == "recompute"
+        assert PF.resolve_mode("fused", "heat3d", big) == "stored"               # fused_slower and auto_stored
         assert PF.resolve_mode("auto", "heat3d", big) == "stored"                # auto_stored
     finally:
         PF.SMALL_FIELD_ELEMENTS = small

@@ -44,6 +44,7 @@ CASES = [
     ("C3 GrayScott fd4 (8/GPU)", "GrayScottPDELoss", dict(laplacian="fd4"), (8, 9, 128, 128), lambda B: {}),
     ("C3 GrayScott fft (8/GPU)", "GrayScottPDELoss", dict(), (8, 9, 128, 128), lambda B: {}),
     ("GrayScott fd4 B=64", "GrayScottPDELoss", dict(laplacian="fd4"), (64, 9, 128, 128), lambda B: {}),
+    ("GrayScott fft B=64", "GrayScottPDELoss", dict(), (64, 9, 128, 128), lambda B: {}),
     ("C4 RayleighBenard B=16", "RayleighBenardFullPDELoss", dict(), (16, 9, 512, 128), lambda B: dict(kappa=U(B, 1e-4, 1e-2))),
     ("C4 RayleighBenard B=64", "RayleighBenardFullPDELoss", dict(), (64, 9, 512, 128), lambda B: dict(kappa=U(B, 1e-4, 1e-2))),
     ("C4 ShearFlow B=16", "ShearFlowPDELossNPINN", dict(), (16, 9, 256, 512), lambda B: {}),
