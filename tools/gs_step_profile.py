@@ -1,5 +1,5 @@
 import sys, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pde_amd
 dev = torch.device("cuda:0")
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -1,6 +1,6 @@
 """replayed (loss_fn.capture) and eager step times of the small configurations"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pde_amd
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
