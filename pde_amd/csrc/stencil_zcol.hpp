@@ -54,13 +54,20 @@ struct ZColCfg {
   static constexpr bool BWD_OK = false;
 #else
   static constexpr bool BWD_OK = ON && SHAPE_OK && (P::GT0 | P::GT1 | P::GT2) == 0 && P::GTLO == 1 && P::GTHI == 1 &&
-                                 P::ATLO == 0 && P::ATHI == 0 && (P::AH0 | P::AH1 | P::AH2) == 0 &&
+                                 P::ATLO == 0 && P::ATHI == 0 && P::AFPURE != 0 &&
                                  (P::AT0 | P::AT1 | P::AT2) == 0 && P::TIME_AF == 0;
 #endif
+  // the adjoint's field reads: NFL fields at the own cell (a z column of 2 AH0 + 1 planes in registers); when it also
+  // reads them beside the site in (y, x), NFA of them as plane images of the own frame
+  static constexpr int NFL = P::ANY_AF ? P::AFN : 0;
+  static constexpr int NFA = (P::AH1 | P::AH2) != 0 ? NFL : 0;
+  using TA = Tile<1, T1, T2, 0, P::AH1, padw<W>(P::AH2)>;
   // dynamic LDS of a workgroup of nfw frames: the block reduction's slots, then 2 buffers x (nfw + 2) frame slots
   static constexpr size_t RED_BYTES = 16 * MAXE * sizeof(double);
   static size_t fwd_lds(int nfw) { return RED_BYTES + 2ul * (nfw + 2) * P::NF * TP::SIZE * sizeof(float); }
-  static size_t bwd_lds(int nfw) { return RED_BYTES + 2ul * (nfw + 2) * P::NE * TG::SIZE * sizeof(float); }
+  static size_t bwd_lds(int nfw) {
+    return RED_BYTES + 2ul * ((nfw + 2) * P::NE * TG::SIZE + nfw * NFA * TA::SIZE) * sizeof(float);
+  }
 };
 
 // A lane offset no buffer of these kernels reaches (they are launched for clips of at most 2 GiB per field): loads through
@@ -346,13 +353,14 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
 // ------------------------------------------------------------------------------------------------
 // adjoint from stored residuals
 // ------------------------------------------------------------------------------------------------
-template <class P, class TG, int W>
+template <class P, class TG, class TA, int W>
 struct ZColAdjAcc : SiteBase<P> {
   using fv = typename VecOf<W>::type;
-  static constexpr int NZ = 2 * P::GH0 + 1;
+  static constexpr int NZ = 2 * P::GH0 + 1, NZA = 2 * P::AH0 + 1;
   const float* site;         // &image[this frame's slot][equation 0][own row][own cell]
+  const float* fsite;        // &field image[this frame][field 0][own row][own cell] (PDEs whose adjoint reads fields beside the site)
   fv gcol[P::NE][NZ];        // the cell's scaled residuals at planes k - GH0 .. k + GH0
-  fv fq[P::NF];              // the cell's fields at plane k
+  fv fcol[P::NF][NZA];       // the cell's fields at planes k - AH0 .. k + AH0
   int px;
   __device__ __forceinline__ float G(int k, int ot, int o0, int o1, int o2) const {
     if (ot != 0) {
@@ -365,7 +373,13 @@ struct ZColAdjAcc : SiteBase<P> {
     const fv v = *reinterpret_cast<const fv*>(site + k * TG::SIZE + o1 * TG::S1 + W * qd);
     return v[e];
   }
-  __device__ __forceinline__ float F(int f, int, int, int, int) const { return fq[f][px]; }
+  __device__ __forceinline__ float F(int f, int, int o0, int o1, int o2) const {
+    if (o0 != 0) return fcol[f][o0 + P::AH0][px];
+    PDE_AMD_QUAD_SPLIT(px + o2, qd, e)
+    if (o1 == 0 && qd == 0) return fcol[f][P::AH0][e];
+    const fv v = *reinterpret_cast<const fv*>(fsite + f * TA::SIZE + o1 * TA::S1 + W * qd);
+    return v[e];
+  }
   __device__ __forceinline__ float X(int, int, int, int) const { return 0.0f; }
 };
 
@@ -391,10 +405,12 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
   using C = ZColCfg<P, W>;
   using TG = typename C::TG;
   using fv = typename VecOf<W>::type;
+  using TA = typename C::TA;
   using HC = HaloCells<TG, W, C::LPF>;
+  using HA = HaloCells<TA, W, C::LPF>;
   constexpr int LPF = C::LPF, GH0 = P::GH0, NZ = 2 * GH0 + 1, NF = P::NF, NE = P::NE, QR = C::QR, EPT = HC::EPT;
+  constexpr int NFL = C::NFL, NFA = C::NFA, AH0 = P::AH0, NZA = 2 * AH0 + 1, EPA = HA::EPT;
   constexpr int NED = SOLO ? 2 : 1;
-  constexpr bool AF = P::ANY_AF != 0;
   static_assert(C::BWD_OK, "PDE not eligible for the z-column stored-residual adjoint");
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   float* s_img = reinterpret_cast<float*>(s_raw + C::RED_BYTES);
@@ -410,7 +426,8 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
   const int o2 = (it.tile % g.nt2) * TG::T2, o1 = (it.tile / g.nt2) * TG::T1;
   const int za = it.zc * a.chunk, zb = min(za + a.chunk, g.N0);
   const unsigned plane4 = 4u * (unsigned)(g.N1 * g.N2), frame4 = 4u * (unsigned)g.S;
-  const int bufsz = (nfw + 2) * NE * TG::SIZE;
+  const int bufsz = (nfw + 2) * NE * TG::SIZE, fbufsz = nfw * NFA * TA::SIZE;
+  float* s_fimg = s_img + 2 * bufsz;      // field images of the frames of the group, two buffers
 
   const int row = lid / QR, l2 = W * (lid % QR);
   const int pi1 = o1 + row, pi2 = o2 + l2;
@@ -424,12 +441,16 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
   const unsigned soff = live && inside ? 4u * (unsigned)(pi1 * g.N2 + pi2) : ZC_NOWHERE;
   // the clip's first / last frame get their gradient from the waves of the first / last residual frame
   const unsigned soff_first = tr == 0 ? soff : ZC_NOWHERE, soff_last = tr == g.TR - 1 ? soff : ZC_NOWHERE;
-  const int olds = TG::at(0, row, l2);
+  const int olds = TG::at(0, row, l2), oldsa = TA::at(0, row, l2);
   HC hc;
   hc.init(lid, o1, o2, g);
+  HA ha;
+  ha.init(lid, o1, o2, g);
   if (!live) {
 #pragma unroll
     for (int j = 0; j < EPT; ++j) hc.goff[j] = ZC_NOWHERE;
+#pragma unroll
+    for (int j = 0; j < EPA; ++j) ha.goff[j] = ZC_NOWHERE;
   }
 
   __amdgpu_buffer_rsrc_t rbuf[NE], fbuf[NF], gbuf[NF];
@@ -472,7 +493,7 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
     }
   }
 
-  ZColAdjAcc<P, TG, W> acc;
+  ZColAdjAcc<P, TG, TA, W> acc;
   acc.template set_uniforms<true>(a.c, a.sp, it.b);
   acc.N0 = g.N0; acc.N1 = g.N1; acc.N2 = g.N2;
   acc.i1 = pi1;
@@ -481,9 +502,10 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
   eacc.N0 = g.N0; eacc.N1 = g.N1; eacc.N2 = g.N2;
   eacc.i1 = pi1;
 
-  fv hal[NE][EPT], edg[NED][NE], nxt[NE], fnx[NF];
-  PlaneCursor<true> cur;
+  fv hal[NE][EPT], edg[NED][NE], nxt[NE], fnx[NFL > 0 ? NFL : 1], fhal[NFA > 0 ? NFA : 1][EPA];
+  PlaneCursor<true> cur, curf;      // the planes the columns take in next: k + 1 + GH0 (residuals), k + 1 + AH0 (fields)
   cur.init(za + GH0 + 1, g.N0, 1);
+  curf.init(za + AH0 + 1, g.N0, 1);
   {
     bool on;
 #pragma unroll
@@ -493,6 +515,12 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
       for (int e = 0; e < NE; ++e) acc.gcol[e][i] = BufIO<W>::load(rbuf[e], ooff, rfr + pz);
     }
 #pragma unroll
+    for (int i = 0; i < NZA; ++i) {
+      const unsigned pz = (unsigned)z_plane<true>(za - AH0 + i, g.N0, on) * plane4;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc.fcol[f][i] = f < NFL ? BufIO<W>::load(fbuf[f], ooff, fr + pz) : vec_zero<W>();
+    }
+#pragma unroll
     for (int e = 0; e < NE; ++e) {
 #pragma unroll
       for (int j = 0; j < EPT; ++j) hal[e][j] = BufIO<W>::load(rbuf[e], hc.goff[j], rfr + (unsigned)za * plane4);
@@ -500,14 +528,17 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
       for (int s = 0; s < NED; ++s) edg[s][e] = BufIO<W>::load(rbuf[e], eoff[s], efr[s] + (unsigned)za * plane4);
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) fnx[f] = AF ? BufIO<W>::load(fbuf[f], ooff, fr + (unsigned)za * plane4) : vec_zero<W>();
+    for (int f = 0; f < NFA; ++f) {
+#pragma unroll
+      for (int j = 0; j < EPA; ++j) fhal[f][j] = BufIO<W>::load(fbuf[f], ha.goff[j], fr + (unsigned)za * plane4);
+    }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
 #pragma unroll
       for (int i = 0; i < NZ; ++i) acc.gcol[e][i] = acc.gcol[e][i] * cf[e];
     }
   }
-  auto write_image = [&](float* img) __attribute__((always_inline)) {
+  auto write_image = [&](float* img, float* fimg) __attribute__((always_inline)) {
     if (!live) return;
     float* mine = img + (fw + 1) * NE * TG::SIZE;
 #pragma unroll
@@ -520,14 +551,21 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
       for (int s = 0; s < NED; ++s)
         if (ewr[s]) *reinterpret_cast<fv*>(img + (eslot[s] * NE + e) * TG::SIZE + olds) = edg[s][e] * ecf[s][e];
     }
+    float* fmine = fimg + fw * NFA * TA::SIZE;
+#pragma unroll
+    for (int f = 0; f < NFA; ++f) {
+      *reinterpret_cast<fv*>(fmine + f * TA::SIZE + oldsa) = acc.fcol[f][AH0];
+#pragma unroll
+      for (int j = 0; j < EPA; ++j)
+        if (ha.lds[j] >= 0) *reinterpret_cast<fv*>(fmine + f * TA::SIZE + ha.lds[j]) = fhal[f][j];
+    }
   };
-  write_image(s_img);
+  write_image(s_img, s_fimg);
   unsigned ko = (unsigned)za * plane4;
 
   for (int k = za; k < zb; ++k) {
     float* img = s_img + ((k - za) & 1) * bufsz;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) acc.fq[f] = fnx[f];
+    float* fimg = s_fimg + ((k - za) & 1) * fbufsz;
     __syncthreads();
     const unsigned kn = k + 1 < zb ? ko + plane4 : ko;
 #ifndef PDE_AMD_ZC_NOLOAD
@@ -539,18 +577,23 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
 #pragma unroll
       for (int s = 0; s < NED; ++s) edg[s][e] = BufIO<W>::load(rbuf[e], eoff[s], efr[s] + kn);
     }
-    if (AF) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) fnx[f] = BufIO<W>::load(fbuf[f], ooff, fr + kn);
+    for (int f = 0; f < NFL; ++f) fnx[f] = BufIO<W>::load(fbuf[f], ooff, fr + (unsigned)curf.p * plane4);
+#pragma unroll
+    for (int f = 0; f < NFA; ++f) {
+#pragma unroll
+      for (int j = 0; j < EPA; ++j) fhal[f][j] = BufIO<W>::load(fbuf[f], ha.goff[j], fr + kn);
     }
 #else      // ablation (wrong results): no global loads inside the loop
 #pragma unroll
     for (int e = 0; e < NE; ++e) nxt[e] = acc.gcol[e][0];
 #endif
     cur.advance(g.N0, 1);
+    curf.advance(g.N0, 1);
     {
       acc.i0 = k;
       acc.site = img + (fw + 1) * NE * TG::SIZE + olds;
+      acc.fsite = fimg + fw * NFA * TA::SIZE + oldsa;
       fv out[NF];
 #pragma unroll
       for (int px = 0; px < W; ++px) {
@@ -598,8 +641,14 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
       for (int i = 0; i + 1 < NZ; ++i) acc.gcol[e][i] = acc.gcol[e][i + 1];
       acc.gcol[e][NZ - 1] = nxt[e] * cf[e];
     }
+#pragma unroll
+    for (int f = 0; f < NFL; ++f) {
+#pragma unroll
+      for (int i = 0; i + 1 < NZA; ++i) acc.fcol[f][i] = acc.fcol[f][i + 1];
+      acc.fcol[f][NZA - 1] = fnx[f];
+    }
     ko += plane4;
-    write_image(s_img + ((k + 1 - za) & 1) * bufsz);
+    write_image(s_img + ((k + 1 - za) & 1) * bufsz, s_fimg + ((k + 1 - za) & 1) * fbufsz);
   }
 }
 

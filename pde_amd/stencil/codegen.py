@@ -153,6 +153,11 @@ def emit_spec(s: Spec) -> str:
     L.append(f"  // which fields the residuals read at other frames (the others need one LDS frame slot, not a ring)")
     L.append(f"  static __host__ __device__ constexpr int tuse(int f) {{ return " + " : ".join(f"f == {i} ? {v}" for i, v in enumerate(tuse)) + " : 0; }")
     L.append(f"  static constexpr int TIME_AF = {1 if time_f else 0};   // the other-frame adjoint terms read fields")
+    arefs = [n for e in s.adjoint for n in collect(e, Ref).values()]
+    afn = 1 + max((n.f for n in arefs), default=-1)
+    apure = all(n.ot == 0 and sum(1 for o in n.o if o != 0) <= 1 for n in arefs)
+    L.append(f"  static constexpr int AFN = {afn}, AFPURE = {1 if apure else 0};   // fields 0 .. AFN-1 are what the adjoint reads; "
+             f"AFPURE: only at its own frame and at sites on the three axes through the output site")
     tab = UniformTable() if s.hoist_uniforms else None
     body = _emit_fn("residual", "R", ne, s.residuals, tab=tab, share=True)
     body += _emit_fn("adjoint", "g", nf, [fa(e) for e in s.adjoint], tab=tab)
