@@ -316,7 +316,9 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
 #else
         P::residual(acc, Rq[px]);
 #endif
-        const bool ok = zok && rowok && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
+        // (the waves of a short last group's missing frames read image slots nobody wrote: their values are dropped
+        // here by selection, never multiplied by a zero weight)
+        const bool ok = live && zok && rowok && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
 #pragma unroll
         for (int e = 0; e < NE; ++e) Rq[px][e] = ok ? Rq[px][e] : 0.0f;
       }

@@ -150,6 +150,21 @@ def test_ragged_sizes_vs_oracle(cls, kw, shape, ps, mode):
         assert rel_l2(gr.cpu().numpy(), f.grad.numpy()) <= TOL
 
 
+LONG3D = [
+    ("TaylorGreen3DPDELoss", dict(nx=64, ny=16, nz=20, Lx=2.0, Ly=1.0, Lz=3.0, dt=0.01), (1, 17, 20, 16, 64), dict(nu=(0.01, 0.1))),
+    ("APEBenchBurgers3DPDELoss", dict(nx=64, Lx=1.0, dt=1.0), (1, 17, 20, 16, 64), {}),
+    ("Heat3DPDELoss", dict(nx=64, ny=16, nz=20, Lx=1.0, Ly=1.0, Lz=1.0, dt=0.01), (2, 17, 20, 16, 64), dict(alpha=(0.005, 0.05))),
+    ("Advection3DPDELoss", dict(dx=0.1, dy=0.2, dz=0.3, dt=0.05), (2, 12, 20, 16, 64), dict(a=(-1, 1), b=(-1, 1), c=(-1, 1))),
+]
+
+
+@pytest.mark.parametrize("cls,kw,shape,ps", LONG3D, ids=[s[0] for s in LONG3D])
+def test_long_clips_3d_vs_oracle(cls, kw, shape, ps):
+    """Clips of 10 and 15 residual frames on grids the z-column kernels take: several groups of frames per tile, the last
+    one shorter, with the frames between two groups staged by both."""
+    test_ragged_sizes_vs_oracle(cls, kw, shape, ps, "auto")
+
+
 def _whole_tile_variant(entry):
     """Same case on a grid of whole tiles (1-D: 512 points; 2-D: 32 x 128): uncropped periodic classes then take the
     adjoint instantiation that carries no lattice masks."""
