@@ -143,6 +143,10 @@ int pde_amd_time_next_adjoint(void* start_event, void* stop_event);
  * (e.g. "bwd_march_q_kernel<pde_amd::Pde_tg2d, 4, true, true>"): the key under which a measurement of that kernel is
  * filed.  "" before the first such call.  The string lives in thread-local storage of the library. */
 const char* pde_amd_last_adjoint_kernel(void);
+/* Diagnostic, no counterpart in the reference: fills the LDS of the current device's CUs with NaNs (a short kernel on
+ * `stream`).  LDS keeps its contents between kernels, so a kernel that reads LDS it did not write usually sees finite
+ * leftovers; after this call it sees NaNs.  The test-suite runs with it before every launch when PDE_AMD_POISON_LDS=1. */
+int pde_amd_diag_poison_lds(void* stream);
 
 /* grads[f][i] *= *upstream / *assumed for n_fields arrays of `elements` floats; nothing is read or written when the
  * two device scalars are equal (decided on the device, no host synchronisation).  It turns the gradients that

@@ -66,6 +66,7 @@ SIGNATURES = {
                                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "pde_amd_time_next_adjoint": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pde_amd_last_adjoint_kernel": (C.c_char_p, []),
+    "pde_amd_diag_poison_lds": (C.c_int, [C.c_void_p]),
     "pde_amd_rescale_gradients": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pde_amd_pair_stats_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "pde_amd_pair_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p,

@@ -675,6 +675,15 @@ static const PdeVTable* lookup(int id) {
 
 using namespace pde_amd;
 
+// fills the workgroup's whole LDS allocation with NaNs (pde_amd_diag_poison_lds)
+__global__ void poison_lds_kernel(int words) {
+  extern __shared__ float s_poison[];
+  volatile float* p = s_poison;
+  const float nan = __int_as_float(0x7fc00000);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) p[i] = nan;
+  __builtin_amdgcn_s_sleep(32);      // stay resident a moment, so that the workgroups spread over the CUs
+}
+
 extern "C" {
 
 int pde_amd_num_pdes(void) { return kNumPdes; }
@@ -793,6 +802,21 @@ int pde_amd_residual_forward_backward_static(const pde_amd_problem* prob, const 
 }
 
 const char* pde_amd_last_adjoint_kernel(void) { return t_kernel; }
+
+int pde_amd_diag_poison_lds(void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  constexpr int BYTES = 160 * 1024;
+  static bool granted = false;
+  if (!granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES) != hipSuccess)
+      return PDE_AMD_EHIP;
+    granted = true;
+  }
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return PDE_AMD_EHIP;
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(4 * cus), dim3(1024), BYTES, stream, BYTES / 4);      // one workgroup fills a CU's LDS: each CU gets several in turn
+  return hipGetLastError() == hipSuccess ? PDE_AMD_OK : PDE_AMD_EHIP;
+}
 
 #ifdef PDE_AMD_DIAG_ONLY
 // diagnostic builds only: workgroups per CU the runtime grants the z-column kernels of the build's PDE

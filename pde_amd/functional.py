@@ -91,6 +91,15 @@ class HipBackend:
             self._ws[key] = ws
         return ws
 
+    # Diagnostic (PDE_AMD_POISON_LDS=1): NaNs into every CU's LDS before each residual launch, so that a kernel that reads
+    # LDS it did not write fails the parity tests instead of living on finite leftovers.
+    poison_lds = os.environ.get("PDE_AMD_POISON_LDS") == "1"
+
+    def _poison(self, t: torch.Tensor):
+        if self.poison_lds:
+            with self._on(t.device):
+                _lib.check(_lib.lib().pde_amd_diag_poison_lds(self._stream(t)), "diag_poison_lds")
+
     @staticmethod
     def _on(device):
         """Context that makes `device` current for the launch; free when it already is."""
@@ -144,6 +153,7 @@ class HipBackend:
             ev = self.forward_event_pool.pop() if self.forward_event_pool else (
                 torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        self._poison(f0)
         with self._on(f0.device):
             st = L.pde_amd_residual_forward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                             _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()),
@@ -189,6 +199,7 @@ class HipBackend:
         uptr = _lib.ptr_array(upstream, len(s.eqs) + 1) if upstream is not None else None
         gs = C.c_void_p(upstream_sums.data_ptr()) if upstream_sums is not None else None
         ev = self._arm_adjoint_timer()
+        self._poison(f0)
         with self._on(f0.device):
             st = L.pde_amd_residual_backward(C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
                                              _lib.ptr_array(sparams, len(sparams)), C.c_void_p(weights.data_ptr()), uptr, gs,
@@ -213,6 +224,7 @@ class HipBackend:
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
         ev = self._arm_adjoint_timer()      # the adjoint kernel does the whole step here
+        self._poison(f0)
         with self._on(f0.device):
             st = L.pde_amd_residual_forward_backward(
                 C.byref(cp), _lib.ptr_array(fields, len(fields)), _lib.ptr_array(aux, len(aux)),
@@ -248,7 +260,7 @@ def _use_op() -> bool:
     says so once and drives the same kernels from the Python autograd function.  The kernel library itself is required
     either way."""
     global _OP_OK
-    if _HOST == "ctypes":
+    if _HOST == "ctypes" or HipBackend.poison_lds:      # the diagnostic hooks sit in the Python launcher
         return False
     if _OP_OK is None:
         try:
