@@ -452,6 +452,8 @@ def _spectral_pair_apply(a: torch.Tensor, b: torch.Tensor, mult: torch.Tensor):
     planes = a.numel() // (nx * ny)
     with torch.cuda.device(a.device):
         stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        if HipBackend.poison_lds:
+            _lib.check(_lib.lib().pde_amd_diag_poison_lds(stream), "diag_poison_lds")
         _lib.check(_lib.lib().pde_amd_spectral_laplacian_pair(a.data_ptr(), b.data_ptr(), la.data_ptr(), lb.data_ptr(), mult.data_ptr(),
                                                               planes, nx, ny, stream), "spectral_laplacian_pair")
     return la, lb

@@ -12,6 +12,7 @@ replace the backend object with an interpreter that lives under tests/.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence
 
 import torch
@@ -22,8 +23,16 @@ NSTAT = _lib.NSTAT
 S_D2, S_G2, S_G, S_P, S_RSE, S_MAXD = range(6)
 
 
+_POISON_LDS = os.environ.get("PDE_AMD_POISON_LDS") == "1"      # diagnostic: NaNs into every CU's LDS before each launch
+
+
 def _stream(t: torch.Tensor):
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """the launch stream as the C ABI takes it (every launch below asks for it right before the call)"""
+    st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if _POISON_LDS:
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.lib().pde_amd_diag_poison_lds(st), "diag_poison_lds")
+    return st
 
 
 def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
