@@ -144,6 +144,25 @@ def torch_op():
     return _torch_op
 
 
+# Diagnostic (PDE_AMD_POISON_LDS=1): every buffer the wrappers hand to a kernel starts as NaNs (all-ones bytes), so an
+# element the kernel was supposed to write and did not shows up in the parity tests.
+POISON = os.environ.get("PDE_AMD_POISON_LDS") == "1"
+
+
+def empty(*size, **kw):
+    t = torch.empty(*size, **kw)
+    if POISON and t.numel():
+        t.view(torch.uint8).fill_(255) if t.dtype is not torch.uint8 else t.fill_(255)
+    return t
+
+
+def empty_like(x):
+    t = torch.empty_like(x)
+    if POISON and t.numel():
+        t.view(torch.uint8).fill_(255)
+    return t
+
+
 def check(status: int, what: str):
     if status != 0:
         msg = lib().pde_amd_status_string(status).decode()

@@ -87,7 +87,7 @@ class HipBackend:
         key = (device, torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            ws = _lib.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
             self._ws[key] = ws
         return ws
 
@@ -139,14 +139,14 @@ class HipBackend:
         B, T = f0.shape[0], f0.shape[1]
         TR = max(T - s.tlo - s.thi, 0)
         ne = len(s.eqs)
-        sums = torch.empty((B, ne), dtype=torch.float64, device=f0.device)
+        sums = _lib.empty((B, ne), dtype=torch.float64, device=f0.device)
         totals = new_totals(ne, f0.device)
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
         resid = None
         rptr = None
         if store_residuals:
-            resid = [torch.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float32, device=f0.device) for _ in range(ne)]
+            resid = [_lib.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float32, device=f0.device) for _ in range(ne)]
             rptr = _lib.ptr_array(resid, ne)
         ev = None
         if self.forward_events is not None:
@@ -175,9 +175,9 @@ class HipBackend:
         cp = prob.c_struct(f0.shape)
         B, T = f0.shape[0], f0.shape[1]
         TR, ne = max(T - s.tlo - s.thi, 0), len(s.eqs)
-        sums = torch.empty((B, ne), dtype=torch.float64, device=f0.device)
-        totals = torch.empty((ne + 1,), dtype=torch.float64, device=f0.device)
-        resid = [torch.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float64, device=f0.device) for _ in range(ne)]
+        sums = _lib.empty((B, ne), dtype=torch.float64, device=f0.device)
+        totals = _lib.empty((ne + 1,), dtype=torch.float64, device=f0.device)
+        resid = [_lib.empty((B, TR) + tuple(f0.shape[2:]), dtype=torch.float64, device=f0.device) for _ in range(ne)]
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
         consts = (C.c_double * max(len(prob.consts), 1))(*[float(v) for v in prob.consts])
@@ -194,7 +194,7 @@ class HipBackend:
         L = _lib.lib()
         s = SPECS[prob.spec]
         cp = prob.c_struct(f0.shape)
-        grads = [torch.empty_like(f) for f in fields]
+        grads = [_lib.empty_like(f) for f in fields]
         rptr = _lib.ptr_array(resid, len(resid)) if resid is not None else None
         uptr = _lib.ptr_array(upstream, len(s.eqs) + 1) if upstream is not None else None
         gs = C.c_void_p(upstream_sums.data_ptr()) if upstream_sums is not None else None
@@ -218,9 +218,9 @@ class HipBackend:
         s = SPECS[prob.spec]
         cp = prob.c_struct(f0.shape)
         ne = len(s.eqs)
-        sums = torch.empty((f0.shape[0], ne), dtype=torch.float64, device=f0.device)
+        sums = _lib.empty((f0.shape[0], ne), dtype=torch.float64, device=f0.device)
         totals = new_totals(ne, f0.device)
-        grads = [torch.empty_like(f) for f in fields]
+        grads = [_lib.empty_like(f) for f in fields]
         ws_bytes = L.pde_amd_residual_workspace_bytes(C.byref(cp))
         ws = self._workspace(f0.device, ws_bytes)
         ev = self._arm_adjoint_timer()      # the adjoint kernel does the whole step here
@@ -302,7 +302,7 @@ def new_totals(ne: int, device, dtype=torch.float32) -> torch.Tensor:
     """The vector a residual-loss call writes its scalars to: the one named by an enclosing totals_into, else a fresh one."""
     vec = getattr(_DEST, "vec", None)
     if vec is None or dtype is not torch.float32:
-        return torch.empty((ne + 1,), dtype=dtype, device=device)
+        return _lib.empty((ne + 1,), dtype=dtype, device=device)
     if vec.dtype is not torch.float32 or vec.dim() != 1 or vec.numel() != ne + 1 or not vec.is_contiguous() or vec.device != device \
             or vec.requires_grad:
         raise ValueError(f"totals_into: need a contiguous fp32 vector of {ne + 1} elements on {device} that requires no gradient, "
@@ -448,7 +448,7 @@ def _spectral_pair_apply(a: torch.Tensor, b: torch.Tensor, mult: torch.Tensor):
     nx, ny = a.shape[-2], a.shape[-1]
     if a.shape != b.shape or a.dtype is not torch.float32 or b.dtype is not torch.float32 or tuple(mult.shape) != (nx, ny):
         raise ValueError(f"spectral Laplacian: two fp32 fields of one shape and a multiplier [{nx}, {ny}] expected")
-    la, lb = torch.empty_like(a), torch.empty_like(b)
+    la, lb = _lib.empty_like(a), _lib.empty_like(b)
     planes = a.numel() // (nx * ny)
     with torch.cuda.device(a.device):
         stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)

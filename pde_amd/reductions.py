@@ -65,9 +65,9 @@ class HipReductions:
         pred, target = _f32c(pred, "pred"), _f32c(target, "target")
         if pred.numel() != groups * rows * channels or target.numel() != pred.numel():
             raise ValueError(f"pair_stats: {tuple(pred.shape)} / {tuple(target.shape)} is not [{groups}, {rows}, {channels}]")
-        stats = torch.empty((groups, channels, NSTAT), dtype=torch.float64, device=pred.device)
+        stats = _lib.empty((groups, channels, NSTAT), dtype=torch.float64, device=pred.device)
         nbytes = l.pde_amd_pair_stats_workspace_bytes(groups, rows, channels)
-        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
+        ws = _lib.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
         sc, sh, _ = _affine_args(affine, groups)
         if affine is not None and tuple(affine[0].shape) != (groups, channels):
             raise ValueError(f"pair_stats: the affine map must be [{groups}, {channels}], got {tuple(affine[0].shape)}")
@@ -85,12 +85,12 @@ class HipReductions:
         rows = pred.numel() // max(B * Cn, 1)
         if target.shape != pred.shape or input_data.shape[0] != B or tuple(input_data.shape[2:]) != spatial + (Cn,):
             raise ValueError("pair_stats_gather: pred, target [B, T, *spatial, C] and input_data [B, T_in, *spatial, C] do not match")
-        stats = torch.empty((B, Cn, NSTAT), dtype=torch.float64, device=pred.device)
-        fields = [torch.empty((B, T + 1) + spatial, dtype=torch.float32, device=pred.device) for _ in channels]
+        stats = _lib.empty((B, Cn, NSTAT), dtype=torch.float64, device=pred.device)
+        fields = [_lib.empty((B, T + 1) + spatial, dtype=torch.float32, device=pred.device) for _ in channels]
         for f, c in zip(fields, channels):      # frame 0: a strip of the input (the gather of the reference's preamble)
             f[:, 0].copy_(input_data[:, 0, ..., int(c)])
         nbytes = l.pde_amd_pair_stats_workspace_bytes(B, rows, Cn)
-        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
+        ws = _lib.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
         sc, sh, _ = _affine_args(affine, B)
         ch = (C.c_int32 * max(len(channels), 1))(*[int(c) for c in channels])
         _lib.check(l.pde_amd_pair_stats_gather(pred.data_ptr(), target.data_ptr(), B, rows, Cn, -1.0, sc, sh, stats.data_ptr(), T, ch,
@@ -100,7 +100,7 @@ class HipReductions:
 
     def vrmse_from_stats(self, stats, valid: Sequence[int], rows: int):
         """[2] fp32 (vrmse, rmse) from one group's statistics [C, NSTAT]; at most 64 valid channels."""
-        out = torch.empty(2, dtype=torch.float32, device=stats.device)
+        out = _lib.empty(2, dtype=torch.float32, device=stats.device)
         arr = (C.c_int32 * max(len(valid), 1))(*[int(v) for v in valid])
         _lib.check(_lib.lib().pde_amd_vrmse_from_stats(stats.data_ptr(), int(stats.shape[0]), arr, len(valid), int(rows),
                                                        out.data_ptr(), _stream(stats)), "vrmse_from_stats")
@@ -127,9 +127,9 @@ class HipReductions:
     def terms_forward(self, pred, target, outer: int, dims: Sequence[int], terms, indices, affine=None):
         """affine = (scale[B, C], shift[B, C]) reads pred as pred * scale + shift per sample and channel."""
         l = _lib.lib()
-        sums = torch.empty(len(terms), dtype=torch.float64, device=pred.device)
+        sums = _lib.empty(len(terms), dtype=torch.float64, device=pred.device)
         nbytes = l.pde_amd_terms_workspace_bytes(len(terms))
-        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
+        ws = _lib.empty(max(nbytes, 8), dtype=torch.uint8, device=pred.device)
         d = (C.c_int32 * 4)(*[int(v) for v in dims])
         sc, sh, ops = _affine_args(affine, outer)
         _lib.check(l.pde_amd_terms_forward_affine(pred.data_ptr(), target.data_ptr() if target is not None else None, outer, d,
@@ -157,7 +157,7 @@ class HipReductions:
             S *= v
         rows, cols = (spatial[-2], spatial[-1]) if len(spatial) >= 2 else (1, 1)
         fshape = spatial[:-2] + [cols, rows] if transpose else spatial
-        fields = [torch.empty([B, T_out + 1] + fshape, dtype=torch.float32, device=output.device) for _ in channels]
+        fields = [_lib.empty([B, T_out + 1] + fshape, dtype=torch.float32, device=output.device) for _ in channels]
         ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
         sc, sh, _ = _affine_args(affine, B)
         _lib.check(l.pde_amd_gather_fields_affine(output.data_ptr(), input_data.data_ptr(), B, T_out, T_in, S, Cn, ch, len(channels),
@@ -174,7 +174,7 @@ class HipReductions:
         for v in spatial:
             S *= v
         rows, cols = (spatial[-2], spatial[-1]) if len(spatial) >= 2 else (1, 1)
-        gout = torch.empty(list(out_shape), dtype=torch.float32, device=grads[0].device)
+        gout = _lib.empty(list(out_shape), dtype=torch.float32, device=grads[0].device)
         ch = (C.c_int32 * len(channels))(*[int(c) for c in channels])
         _lib.check(l.pde_amd_scatter_field_grads_affine(_lib.ptr_array(grads, len(grads)), B, T_out, S, Cn, ch, len(channels),
                                                         rows, cols, int(bool(transpose)), scale.data_ptr() if scale is not None else None,
