@@ -653,9 +653,12 @@ struct Ops {
 #define PDE_AMD_DIAG_ZCOL PDE_AMD_DIAG_ONLY::ZCOL
 #define PDE_AMD_DIAG_ZCOLF PDE_AMD_DIAG_ONLY::ZCOLF
 #endif
+#ifndef PDE_AMD_DIAG_ZCOLV
+#define PDE_AMD_DIAG_ZCOLV PDE_AMD_DIAG_ONLY::ZCOLV
+#endif
 struct DiagPde : PDE_AMD_DIAG_ONLY {
   static constexpr int ZCW = PDE_AMD_DIAG_ZCW, ZCWB = PDE_AMD_DIAG_ZCWB, ZCT1 = PDE_AMD_DIAG_ZCT1, ZCT2 = PDE_AMD_DIAG_ZCT2;
-  static constexpr int ZCOL = PDE_AMD_DIAG_ZCOL, ZCOLF = PDE_AMD_DIAG_ZCOLF;
+  static constexpr int ZCOL = PDE_AMD_DIAG_ZCOL, ZCOLF = PDE_AMD_DIAG_ZCOLF, ZCOLV = PDE_AMD_DIAG_ZCOLV;
 };
 #define PDE_AMD_VT(P) Ops<DiagPde>::vtable(),
 #else

@@ -316,9 +316,7 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
 #else
         P::residual(acc, Rq[px]);
 #endif
-        // (the waves of a short last group's missing frames read image slots nobody wrote: their values are dropped
-        // here by selection, never multiplied by a zero weight)
-        const bool ok = live && zok && rowok && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
+        const bool ok = zok && rowok && acc.i2 >= g.lo2 && acc.i2 < g.N2 - g.hi2;
 #pragma unroll
         for (int e = 0; e < NE; ++e) Rq[px][e] = ok ? Rq[px][e] : 0.0f;
       }
@@ -327,7 +325,9 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
         float part = 0.0f;
 #pragma unroll
         for (int px = 0; px < W; ++px) part += Rq[px][e] * Rq[px][e];
-        sum[e] += (double)part * (double)wk[e];      // fp32 over the cell, fp64 across planes
+        // fp32 over the cell, fp64 across planes.  The waves of a short last group's missing frames read image slots nobody
+        // wrote: what they computed is dropped by selection, never multiplied by a zero weight.
+        sum[e] += live ? (double)part * (double)wk[e] : 0.0;
       }
       if (WRITE_R) {
 #pragma unroll

@@ -537,7 +537,7 @@ def _heat3d():
     lap = _d2c2(b, u, 0, "dx") + _d2c2(b, u, 1, "dy") + _d2c2(b, u, 2, "dz")
     # forward and adjoint on the plane-marching kernels, residuals stored: step 0.125 ms on [2, 9, 128^3] against 0.171 ms
     # for the time-marching forward + recomputing adjoint and 0.149 ms for the fused step
-    return b.done([_ddt(b, u) - al * lap], **{**T3D, **Z3D, "z_first": True, "auto_stored": True, "fused_slower": True, "zcol": True, "zc_width": 4, "zc_width_bwd": 4})      # [2, 9, 128^3]: stored 0.125 ms, one pass 0.139, recompute 0.166
+    return b.done([_ddt(b, u) - al * lap], **{**T3D, **Z3D, "z_first": True, "auto_stored": True, "fused_slower": True, "zcol": True, "zc_width": 4, "zc_width_bwd": 4, "zc_tile": (4, 64)})      # [2, 9, 128^3]: stored 0.125 ms, one pass 0.139, recompute 0.166
 
 
 def _tg3d():
@@ -557,9 +557,9 @@ def _tg3d():
     for ax, phi in enumerate((u, v, w)):
         conv = u * _d1c2(b, phi, 0, "dx") + v * _d1c2(b, phi, 1, "dy") + w * _d1c2(b, phi, 2, "dz")
         res.append(_ddt(b, phi) + conv + _d1c2(b, p, ax, hs[ax]) - nu * lap(phi))
-    # [1, 9, 128^3]: forward writing residuals 137 us in z-column form (4 points per lane) against 153 us plane-marching,
-    # the plain forward stays plane-marching (101 us)
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zc_width": 4, "zc_width_bwd": 2, "zc_tile": (4, 64)})
+    # [1, 9, 128^3], z-column form at 4 points per lane against plane-marching: forward 88 against 101 us, forward writing
+    # residuals 137 against 153 us
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zcol_plain_fwd": True, "zc_width": 4, "zc_width_bwd": 2, "zc_tile": (4, 64)})
 
 
 def _ns_incom():
