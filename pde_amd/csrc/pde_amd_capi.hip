@@ -549,9 +549,9 @@ struct Ops {
       }
       bool launched = false;
       AdjointTimer timer(stream);
-      if constexpr (ZColCfg<P, P::ZCWB>::BWD_OK) {
+      if constexpr (ZColCfg<P, P::ZCWB, true>::BWD_OK) {
         if (zcol_usable<P::ZCWB>(p, fields) && aligned_vec<P::NF, P::ZCWB>(grads) && aligned_vec<P::NE, P::ZCWB>(resid_in)) {
-          using C = ZColCfg<P, P::ZCWB>;
+          using C = ZColCfg<P, P::ZCWB, true>;
           const ZPlan z = plan_zcol<C::LPF, C::FPWB, C::T1, C::T2>(p, a, tr);
           if (p->batch * z.items >= (1L << 31)) return PDE_AMD_ESHAPE;
           if (launch_zcol(p, a, z, C::LPF, bwd_stored_zcol_kernel<P, P::ZCWB, false>, bwd_stored_zcol_kernel<P, P::ZCWB, true>,
@@ -649,6 +649,10 @@ struct Ops {
 #define PDE_AMD_DIAG_ZCT1 PDE_AMD_DIAG_ONLY::ZCT1
 #define PDE_AMD_DIAG_ZCT2 PDE_AMD_DIAG_ONLY::ZCT2
 #endif
+#ifndef PDE_AMD_DIAG_ZCB1
+#define PDE_AMD_DIAG_ZCB1 PDE_AMD_DIAG_ZCT1
+#define PDE_AMD_DIAG_ZCB2 PDE_AMD_DIAG_ZCT2
+#endif
 #ifndef PDE_AMD_DIAG_ZCOL
 #define PDE_AMD_DIAG_ZCOL PDE_AMD_DIAG_ONLY::ZCOL
 #define PDE_AMD_DIAG_ZCOLF PDE_AMD_DIAG_ONLY::ZCOLF
@@ -658,6 +662,7 @@ struct Ops {
 #endif
 struct DiagPde : PDE_AMD_DIAG_ONLY {
   static constexpr int ZCW = PDE_AMD_DIAG_ZCW, ZCWB = PDE_AMD_DIAG_ZCWB, ZCT1 = PDE_AMD_DIAG_ZCT1, ZCT2 = PDE_AMD_DIAG_ZCT2;
+  static constexpr int ZCB1 = PDE_AMD_DIAG_ZCB1, ZCB2 = PDE_AMD_DIAG_ZCB2;
   static constexpr int ZCOL = PDE_AMD_DIAG_ZCOL, ZCOLF = PDE_AMD_DIAG_ZCOLF, ZCOLV = PDE_AMD_DIAG_ZCOLV;
 };
 #define PDE_AMD_VT(P) Ops<DiagPde>::vtable(),
@@ -837,8 +842,8 @@ void pde_amd_diag_zcol_occupancy(void) {
       printf("fwd_zcol nfw=%d threads=%d lds=%zu -> %d workgroups per CU (%s)\n", nfw, C::LPF * nfw, C::fwd_lds(nfw), n, hipGetErrorString(e));
     }
   }
-  if constexpr (ZColCfg<P, P::ZCWB>::BWD_OK) {
-    using C = ZColCfg<P, P::ZCWB>;
+  if constexpr (ZColCfg<P, P::ZCWB, true>::BWD_OK) {
+    using C = ZColCfg<P, P::ZCWB, true>;
     for (int nfw = 1; nfw <= C::FPWB; ++nfw) {
       int n = -1;
       hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bwd_stored_zcol_kernel<P, P::ZCWB, false>, C::LPF * nfw, C::bwd_lds(nfw));

@@ -35,11 +35,12 @@ namespace pde_amd {
 #define PDE_AMD_ZCOL_WPSB 1
 #endif
 
-template <class P, int W>
+// BWD: the adjoint's configuration (its own tile shape; the forward and the adjoint are separate launches)
+template <class P, int W, bool BWD = false>
 struct ZColCfg {
   static constexpr bool ON = P::ND == 3 && P::ZCOL != 0 && P::ZPURE != 0 && P::NA == 0 && P::TLO == 1 && P::THI == 1 &&
                              (P::RT0 | P::RT1 | P::RT2) == 0 && P::PER0 && P::PER1 && P::PER2 && (W == 2 || W == 4);
-  static constexpr int T1 = ON ? P::ZCT1 : 8, T2 = ON ? P::ZCT2 : 32;
+  static constexpr int T1 = ON ? (BWD ? P::ZCB1 : P::ZCT1) : 8, T2 = ON ? (BWD ? P::ZCB2 : P::ZCT2) : 32;
   static constexpr int QR = T2 / W;              // cells (W points) per tile row
   static constexpr int LPF = T1 * QR;            // lanes per frame: one cell each
   // lanes per workgroup at most: it bounds the registers a lane may use (512 lanes: 256, 768: 168, 1024: 128)
@@ -138,6 +139,12 @@ struct ZColLaunch {
   int nfw, ngroups;
 };
 
+// Wave priorities: a wave runs at priority 2 from the point where it starts writing the next plane's images, through the
+// barrier and the issue of the loads for the plane after, and at 0 while it evaluates the stencil.  The images are what
+// every wave of the workgroup waits for at the barrier and the loads are what the step after next waits for, so the
+// arbiter should prefer them to the arithmetic of the other workgroup on the CU (Burgers-3D adjoint 185 -> 169 us,
+// forward writing residuals 120 -> 112 us, advection-3D adjoint 69 -> 53 us; dropping the priority right after the
+// barrier instead: 175 us).
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -302,6 +309,7 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
     for (int f = 0; f < NF; ++f) nxt[f] = acc.col[f][0];
 #endif
     cur.advance(g.N0, 1);
+    __builtin_amdgcn_s_setprio(0);
     {
       acc.i0 = k;
       acc.site = img + (fw + 1) * NF * TP::SIZE + olds;
@@ -346,6 +354,7 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTF), (ZColCfg<P, W>::WPSF)) void
       acc.col[f][NZ - 1] = nxt[f];
     }
     ko += plane4;
+    __builtin_amdgcn_s_setprio(2);      // see the note on wave priorities above the kernels
     write_image(s_img + ((k + 1 - za) & 1) * bufsz);      // plane k + 1 into the buffer nobody reads during this step
   }
   __syncthreads();
@@ -403,8 +412,8 @@ struct ZColEdgeAcc : SiteBase<P> {
 // SOLO as in the forward kernel; the outer slots hold the scaled residuals of the residual frames next to the group, which
 // belong to other groups (zeros where the clip ends).
 template <class P, int W, bool SOLO>
-__global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void bwd_stored_zcol_kernel(const Args a, const ZColLaunch zl) {
-  using C = ZColCfg<P, W>;
+__global__ __launch_bounds__((ZColCfg<P, W, true>::MAXTB), (ZColCfg<P, W, true>::WPSB)) void bwd_stored_zcol_kernel(const Args a, const ZColLaunch zl) {
+  using C = ZColCfg<P, W, true>;
   using TG = typename C::TG;
   using fv = typename VecOf<W>::type;
   using TA = typename C::TA;
@@ -592,6 +601,7 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
 #endif
     cur.advance(g.N0, 1);
     curf.advance(g.N0, 1);
+    __builtin_amdgcn_s_setprio(0);
     {
       acc.i0 = k;
       acc.site = img + (fw + 1) * NE * TG::SIZE + olds;
@@ -650,6 +660,7 @@ __global__ __launch_bounds__((ZColCfg<P, W>::MAXTB), (ZColCfg<P, W>::WPSB)) void
       acc.fcol[f][NZA - 1] = fnx[f];
     }
     ko += plane4;
+    __builtin_amdgcn_s_setprio(2);      // see the note on wave priorities above the kernels
     write_image(s_img + ((k + 1 - za) & 1) * bufsz, s_fimg + ((k + 1 - za) & 1) * fbufsz);
   }
 }

@@ -140,7 +140,7 @@ def emit_spec(s: Spec) -> str:
     L.append(f"  static constexpr int NTQ = {s.threads_quad}, NTQB = {s.threads_quad_bwd or s.threads_quad}, WPSQ = {s.waves_per_simd_quad};")
     L.append(f"  static constexpr int QWF = {s.quad_width_fwd}, QWB = {s.quad_width_bwd}, QPD = {s.quad_prefetch}, WPSF = {s.waves_per_simd_quad_fwd};")
     L.append(f"  static constexpr int ZT1 = {s.z_tile[0]}, ZT2 = {s.z_tile[1]}, NTZ = {s.z_threads}, ZW = {s.z_width}, ZFIRST = {1 if s.z_first else 0};")
-    L.append(f"  static constexpr int ZCOL = {1 if s.zcol else 0}, ZPURE = {1 if s.z_pure else 0}, ZCT1 = {s.zc_tile[0]}, ZCT2 = {s.zc_tile[1]}, ZCW = {s.zc_width}, ZCWB = {s.zc_width_bwd}, ZCOLV = {1 if s.zcol_plain_fwd else 0}, ZCOLF = {1 if s.zcol_stored_fwd else 0};")
+    L.append(f"  static constexpr int ZCOL = {1 if s.zcol else 0}, ZPURE = {1 if s.z_pure else 0}, ZCT1 = {s.zc_tile[0]}, ZCT2 = {s.zc_tile[1]}, ZCB1 = {(s.zc_tile_bwd or s.zc_tile)[0]}, ZCB2 = {(s.zc_tile_bwd or s.zc_tile)[1]}, ZCW = {s.zc_width}, ZCWB = {s.zc_width_bwd}, ZCOLV = {1 if s.zcol_plain_fwd else 0}, ZCOLF = {1 if s.zcol_stored_fwd else 0};")
     L.append(f"  static constexpr const char* NAME = \"{s.name}\";")
     parts = [split_adjoint(e) for e in s.adjoint]
     fa = (lambda e: factor_pointwise(e)) if s.factor_adjoint else (lambda e: e)

@@ -11,7 +11,7 @@ Per-instance constants are folded on the host in double precision and rounded on
 from __future__ import annotations
 
 from dataclasses import dataclass, field as dc_field
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 from .expr import E, Ref, GRef, adjoint_exprs, collect, footprint
 from .ops import (Q, C2_D1, C2_D2, C4_D1, C4_D2, D4_5PT, KDV_D3, KDV_D4, aux, const, dt_central,
@@ -59,6 +59,7 @@ class Spec:
     zcol_plain_fwd: bool = False    # ... and so does the forward that stores no residuals (measured per PDE)
     zcol_stored_fwd: bool = True    # False: only the adjoint takes them, the forward that stores residuals keeps its kernel
     zc_tile: Tuple[int, int] = (8, 32)
+    zc_tile_bwd: Optional[Tuple[int, int]] = None      # the adjoint's tile when it differs
     zc_width: int = 2               # points per lane of the forward ...
     zc_width_bwd: int = 2           # ... and of the adjoint
     auto_stored: bool = False       # backward modes 'auto' and 'fused' take the stored-residual kernels although the PDE can recompute
@@ -513,7 +514,7 @@ def _ape_burgers3d():
         res.append(_ddt(b, phi) + b1 * conv - a2 * lap(phi))
     # per-frame kernels (the time ring of 3-D halo tiles does not fit LDS): a near-cubic tile reads 3.4 halo floats per
     # point instead of 5.1 and leaves room for three workgroups per CU
-    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zcol_plain_fwd": True, "zc_width": 4, "zc_width_bwd": 2, "zc_tile": (4, 64), "factor_adjoint": True})
+    return b.done(res, **{**T3D, "quad_fwd": (8, 8, 16), "quad_bwd": (8, 8, 16), **Z3D, "zcol": True, "zcol_plain_fwd": True, "zc_width": 4, "zc_width_bwd": 4, "zc_tile": (4, 64), "zc_tile_bwd": (8, 32), "factor_adjoint": True})
 
 
 def _swift_hohenberg3d():
